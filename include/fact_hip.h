@@ -1,0 +1,148 @@
+/* fact_hip.h — C ABI of the MI355X-native FACT engine (libfact_hip.so).
+ *
+ * The reference (google-research/mint) is pure Python/TF and has no FFI; this ABI is the boundary
+ * a maintainer binds (ctypes) to replace what `model_builder.build()` returns
+ * (mint/core/model_builder.py:29-33) and what `SingleTaskTrainer.train_step.train_fn` executes
+ * (mint/ctl/single_task_trainer.py:141-196).  Each entry point names the reference code it replaces.
+ *
+ * Conventions: plain pointers and sizes only (no torch types). All tensor arguments are DEVICE
+ * pointers, row-major, float32 unless stated. All work is enqueued on the caller's `stream`
+ * (a hipStream_t passed as void*); no hidden synchronisation except where documented.
+ * Return value: 0 = ok, negative = error (fact_last_error() gives the message).  One handle per
+ * GPU per process; a handle is not thread-safe.
+ */
+#ifndef FACT_HIP_H_
+#define FACT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FACT_ABI_VERSION 1
+
+/* One transformer stack (mint/core/base_models.py:91-110) plus the modality it embeds. */
+typedef struct FactStackCfg {
+  int seq_len;      /* Modality.sequence_length (model.proto:37-44) */
+  int feature_dim;  /* width of the raw input features (225 motion / 35 audio) */
+  int hidden;       /* Transformer.hidden_size */
+  int layers;       /* Transformer.num_hidden_layers */
+  int heads;        /* Transformer.num_attention_heads */
+  int ff;           /* Transformer.intermediate_size (proto default 3072) */
+} FactStackCfg;
+
+/* FACTModel hyper-parameters (mint/core/fact_model.py:29-70). cross.seq_len / feature_dim unused. */
+typedef struct FactConfig {
+  FactStackCfg motion;
+  FactStackCfg audio;
+  FactStackCfg cross;
+  int out_dim;   /* CrossModalModel.output_layer.out_dim (225) */
+  float ln_eps;  /* 1e-5, base_models.py:27 */
+} FactConfig;
+
+typedef struct FactHandle FactHandle;
+
+/* One trainable tensor, in Keras `trainable_variables` order; `offset` in floats into the arenas.
+ * Dense kernels are [in, out] (rows=in, cols=out) exactly like Keras. */
+typedef struct FactParamDesc {
+  char name[96];
+  size_t offset;
+  int rows;
+  int cols;
+  int kind; /* 0 = dense kernel, 1 = bias, 2 = LN gamma, 3 = LN beta, 4 = position table */
+} FactParamDesc;
+
+/* Caller-owned arenas (optional): param/grad/adam_m/adam_v, each `arena_floats` floats. */
+typedef struct FactArenas {
+  float* params;
+  float* grads;
+  float* adam_m;
+  float* adam_v;
+} FactArenas;
+
+int fact_abi_version(void);
+const char* fact_last_error(void);
+
+/* Number of floats in each arena (padded, 16-byte aligned tensors) and number of tensors. */
+int fact_arena_size(const FactConfig* cfg, size_t* arena_floats, int* n_tensors);
+
+/* Replaces FACTModel.__init__ (fact_model.py:29-70). `arenas` may be NULL (library allocates).
+ * Validates the config the way the reference does: equal hidden sizes for the cross-modal concat
+ * (base_models.py:184-189) -> -2.  `max_batch` sizes the workspaces; `training` != 0 keeps
+ * per-layer activations for the backward pass. */
+int fact_create(const FactConfig* cfg, int max_batch, int training, const FactArenas* arenas,
+                FactHandle** out);
+int fact_destroy(FactHandle* h);
+
+/* Parameter table / arena pointers (device). */
+int fact_param_table(FactHandle* h, const FactParamDesc** table, int* n);
+int fact_arenas(FactHandle* h, FactArenas* out, size_t* arena_floats);
+
+/* Rebuild the bf16 weight shadows from the fp32 master parameters (call after writing params). */
+int fact_refresh_weights(FactHandle* h, void* stream);
+
+/* Replaces FACTModel.call (fact_model.py:72-101): motion (B, n_m, F_m), audio (B, n_a, F_a)
+ * -> out (B, n_m + n_a, out_dim). */
+int fact_forward(FactHandle* h, const float* motion, const float* audio, int B, float* out,
+                 void* stream);
+
+/* Replaces the tape section of train_fn (single_task_trainer.py:141-178): forward, loss
+ * (fact_model.py:143-148; target (B, T, out_dim)), backward.  Gradients of (loss * loss_scale)
+ * are ACCUMULATED into the grad arena (loss_scale = 1/num_replicas, single_task_trainer.py:158).
+ * `loss_out` (device float[1]) receives the unscaled mean-squared error. */
+int fact_forward_backward(FactHandle* h, const float* motion, const float* audio,
+                          const float* target, int B, int T, float loss_scale, float* loss_out,
+                          void* stream);
+
+/* Replaces optimizer.apply_gradients (single_task_trainer.py:186-187) with Keras-Adam semantics
+ * (epsilon outside the bias correction), optional clip_by_global_norm (:180-183; clip_norm <= 0
+ * disables; enabling it synchronises the stream once). Zeroes the grad arena, advances the step
+ * counter and refreshes the bf16 weight shadows. */
+int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps, float clip_norm,
+                   void* stream);
+int fact_get_step(FactHandle* h, int64_t* step);
+int fact_set_step(FactHandle* h, int64_t step);
+
+/* Replaces FACTModel.infer_auto_regressive (fact_model.py:103-132): motion seed (B, n_m, F_m),
+ * audio (B, audio_len, F_a) -> out (B, steps_done, out_dim) with row stride `steps` frames;
+ * steps_done = min(steps, audio_len - n_a + 1) is returned through *steps_done. */
+int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, int B, int audio_len,
+                  int steps, float* out, int* steps_done, void* stream);
+
+/* Engine knobs: key "wgrad_tr" (1 = LDS transpose-read wgrad GEMM, 0 = explicit transposes). */
+int fact_set_option(FactHandle* h, const char* key, int value);
+
+/* ---- single-op entry points (used by the parity tests; same kernels as the model path) ---- */
+/* C = A(MxK) * B^T(NxK) ; epi selects the fused epilogue (see gemm.h); bf16 operands. */
+int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                    void* out0, int ldo0, void* out1, int ldo1, const float* bias, const float* pos,
+                    int seq, const float* resid, int ldr, const void* pre, int ldp, void* stream);
+/* C(MoxNo) += A^T B with A [K][Mo], B [K][No] bf16 (wgrad form), f32 atomic accumulate. */
+int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int No, int K,
+                    float* out, int ldo, int splitk, int use_tr, void* scratch, void* stream);
+int fact_op_ln_fwd(const float* x, const float* gamma, const float* beta, void* h, float* mean,
+                   float* rstd, int M, int C, float eps, void* stream);
+int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
+                   const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
+                   float* dbeta, float* dbias_prev, int M, int C, void* stream);
+/* qkv: bf16 [B*n][3*hid] in (qkv h d) column order -> out bf16 [B*n][hid]; if dout != NULL also
+ * runs the backward and writes dqkv bf16 [B*n][3*hid].  `scratch` >= fact_op_attention_scratch(). */
+size_t fact_op_attention_scratch(int B, int H, int n, int dh);
+int fact_op_attention(const void* qkv, int B, int H, int n, int dh, float scale, void* out,
+                      const void* dout, void* dqkv, void* scratch, void* stream);
+int fact_op_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, float b1, float b2,
+                 float eps, void* stream);
+int fact_op_mse(const float* pred, const float* target, float* loss, void* dpred, int B, int n, int T,
+                int D, int ldp, float gscale, void* stream);
+/* MFMA / LDS-transpose-read layout probes (diagnostics). a_regs/b_regs: f32[64*8] per-lane operand
+ * registers (rounded to bf16), d_regs: f32[64*4].  lds_vals: n<=4096 values placed in LDS as bf16,
+ * byte_addrs: int[64] per-lane LDS byte address, out: f32[64*4] = what each lane received. */
+int fact_probe_mfma(const float* a_regs, const float* b_regs, float* d_regs, void* stream);
+int fact_probe_tr(const float* lds_vals, int n, const int* byte_addrs, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACT_HIP_H_ */

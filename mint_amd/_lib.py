@@ -1,0 +1,109 @@
+"""ctypes binding of libfact_hip.so (the C ABI declared in include/fact_hip.h).
+
+There is deliberately no CPU fallback: if the HIP library is missing or does not load, importing
+this module's `lib()` raises.  The oracle under /oracle is test infrastructure and is never
+imported from the product path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfact_hip.so")
+
+# epilogue kinds (mint_amd/csrc/gemm.h)
+EPI_BF16, EPI_F32_BIAS, EPI_F32_BIAS_POS, EPI_F32_BIAS_RESID = 0, 1, 2, 3
+EPI_BIAS_GELU, EPI_GELU_BWD, EPI_HEADS, EPI_ATOMIC_F32, EPI_F32_BF16 = 4, 5, 6, 7, 8
+
+
+class FactStackCfg(C.Structure):
+    _fields_ = [("seq_len", C.c_int), ("feature_dim", C.c_int), ("hidden", C.c_int),
+                ("layers", C.c_int), ("heads", C.c_int), ("ff", C.c_int)]
+
+
+class FactConfig(C.Structure):
+    _fields_ = [("motion", FactStackCfg), ("audio", FactStackCfg), ("cross", FactStackCfg),
+                ("out_dim", C.c_int), ("ln_eps", C.c_float)]
+
+
+class FactParamDesc(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("offset", C.c_size_t), ("rows", C.c_int),
+                ("cols", C.c_int), ("kind", C.c_int)]
+
+
+class FactArenas(C.Structure):
+    _fields_ = [("params", C.c_void_p), ("grads", C.c_void_p), ("adam_m", C.c_void_p),
+                ("adam_v", C.c_void_p)]
+
+
+# name -> (restype, argtypes); kept in sync with include/fact_hip.h (tests check every symbol)
+_vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+SIGNATURES = {
+    "fact_abi_version": (_i, []),
+    "fact_last_error": (C.c_char_p, []),
+    "fact_arena_size": (_i, [C.POINTER(FactConfig), C.POINTER(_sz), C.POINTER(_i)]),
+    "fact_create": (_i, [C.POINTER(FactConfig), _i, _i, C.POINTER(FactArenas), C.POINTER(_vp)]),
+    "fact_destroy": (_i, [_vp]),
+    "fact_param_table": (_i, [_vp, C.POINTER(C.POINTER(FactParamDesc)), C.POINTER(_i)]),
+    "fact_arenas": (_i, [_vp, C.POINTER(FactArenas), C.POINTER(_sz)]),
+    "fact_refresh_weights": (_i, [_vp, _vp]),
+    "fact_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "fact_forward_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "fact_adam_step": (_i, [_vp, _f, _f, _f, _f, _f, _vp]),
+    "fact_get_step": (_i, [_vp, C.POINTER(C.c_int64)]),
+    "fact_set_step": (_i, [_vp, C.c_int64]),
+    "fact_infer_ar": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
+    "fact_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "fact_op_gemm_nt": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i,
+                             _vp, _i, _vp]),
+    "fact_op_gemm_tn": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "fact_op_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "fact_op_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "fact_op_attention_scratch": (_sz, [_i, _i, _i, _i]),
+    "fact_op_attention": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "fact_op_adam": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
+    "fact_op_mse": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "fact_probe_mfma": (_i, [_vp, _vp, _vp, _vp]),
+    "fact_probe_tr": (_i, [_vp, _i, _vp, _vp, _vp]),
+}
+
+_LIB = None
+
+
+class FactError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libfact_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib():
+    """Load (once) and return the bound library. Raises if the HIP extension is not built."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
+                " (there is no CPU fallback)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = l
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().fact_last_error()
+        raise FactError(rc, msg.decode() if msg else "")
+    return rc
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def cur_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,33 @@
+// Fused (flash-style) full self-attention for FACT on gfx950: non-causal, unmasked,
+// softmax scale = hidden_size^-0.5 (mint/core/base_models.py:66,82-85), MFMA 16x16x32 bf16.
+//
+// All score tiles are computed "transposed" (S^T = K Q^T) so that one query row lives in one
+// lane column: row max / row sum are per-lane scalars plus two wave shuffles, and the bf16 P^T
+// tile is directly the B operand of the O^T = V^T P^T MFMA (no LDS round trip for P).
+//
+// Per-head operand buffers (written by the QKV GEMM epilogue, EPI_HEADS):
+//   *row : [B*H][NP][DHP]  token-major, head dim zero-padded to a multiple of 32
+//   *tr  : [B*H][DH][NP]   head-dim-major (token-contiguous), NP = round_up(n, 128)
+#pragma once
+#include "common.h"
+
+struct AttnParams {
+  const bf16_t* qrow;
+  const bf16_t* krow;
+  const bf16_t* vrow;
+  const bf16_t* qtr;
+  const bf16_t* ktr;
+  const bf16_t* vtr;
+  const bf16_t* dorow;
+  const bf16_t* dotr;
+  bf16_t* out;        // fwd: attention output [B*n][hid] (b n (h d))
+  const bf16_t* o;    // bwd: same tensor, read-only
+  float* lse2;        // [B*H][NP] base-2 log-sum-exp of the scaled scores
+  float* dsum;        // [B*H][NP] rowsum(dO * O)
+  bf16_t* dqkv;       // bwd output [B*n][3*hid] in (qkv h d) column order
+  int B, H, n, NP, hid, dh;
+  float scale;
+};
+
+int launch_attn_fwd(const AttnParams& p, hipStream_t s);
+int launch_attn_bwd(const AttnParams& p, hipStream_t s);  // prep + dQ + dKdV

@@ -1,0 +1,68 @@
+// Common device helpers for the gfx950 (CDNA4 / MI355X) FACT kernels.
+// Wave = 64 lanes. All matrix math uses v_mfma_f32_16x16x32_bf16:
+//   A fragment: lane l holds A[i = l&15][k = (l>>4)*8 + j], j = 0..7   (8 bf16 = 4 VGPR)
+//   B fragment: lane l holds B[k = (l>>4)*8 + j][n = l&15]
+//   C/D       : lane l holds D[row = (l>>4)*4 + r][col = l&15], r = 0..3
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+DEVINL bf16x8 zero_bf16x8() {
+  u32x4 z = {0u, 0u, 0u, 0u};
+  return __builtin_bit_cast(bf16x8, z);
+}
+
+DEVINL bf16x8 ld_global_bf16x8(const bf16_t* p) {
+  return *reinterpret_cast<const bf16x8*>(p);
+}
+
+DEVINL float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+DEVINL float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// tanh-approximation GELU, the reference's form (mint/core/base_model_util.py:94-107):
+//   0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+DEVINL float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));  // tanh(u), saturates cleanly
+  return 0.5f * x * (1.0f + t);
+}
+
+DEVINL float gelu_tanh_grad(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float u = k0 * (x + k1 * x * x2);
+  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
+  float du = k0 * (1.0f + 3.0f * k1 * x2);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
+}
+
+#define HIP_CHECK_RET(expr)                                  \
+  do {                                                       \
+    hipError_t _e = (expr);                                  \
+    if (_e != hipSuccess) return -100 - (int)_e;             \
+  } while (0)

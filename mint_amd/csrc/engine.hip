@@ -1,0 +1,956 @@
+// FACT engine: C-ABI + model orchestration (see include/fact_hip.h).
+//
+// Replaces, for the hot path only, mint/core/{fact_model,base_models}.py and the tape/optimizer
+// section of mint/ctl/single_task_trainer.py:141-196.  Host logic here only sequences kernels on
+// the caller's stream; every FLOP runs in the HIP kernels of gemm.hip / attention.hip / rowops.hip.
+//
+// HBM layout
+//   fp32 arenas (param / grad / adam m / adam v): tensors in Keras trainable_variables order,
+//     Dense kernels [in][out], each tensor offset aligned to 64 floats.
+//   bf16 weight shadows, two per Dense kernel:  s = [in][out_pad]  (dgrad B operand, k = out)
+//                                               t = [out][in_pad]  (fwd   B operand, k = in)
+//   activations: residual stream fp32 [B*n][d]; GEMM operands bf16; per-head q/k/v/dO in both
+//     token-major [B*H][NP][DHP] and head-dim-major [B*H][DH][NP] forms (attention.h).
+#include "../../include/fact_hip.h"
+#include "attention.h"
+#include "gemm.h"
+#include "rowops.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define CHK(expr)                                                                      \
+  do {                                                                                 \
+    int _rc = (expr);                                                                  \
+    if (_rc != 0) return fail(_rc, std::string(#expr) + " failed rc=" + std::to_string(_rc)); \
+  } while (0)
+#define HIPCHK(expr)                                                                        \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) return fail(-100, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+inline size_t rups(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+struct Tensor {
+  size_t off = 0;
+  int rows = 0, cols = 0;
+  size_t numel() const { return (size_t)rows * cols; }
+};
+
+struct DenseW {
+  Tensor w;           // [in][out]
+  bf16_t* s = nullptr;  // [in][lds]
+  bf16_t* t = nullptr;  // [out][ldt]
+  int lds = 0, ldt = 0;
+};
+
+struct LayerP {
+  Tensor ln1_g, ln1_b, bo, ln2_g, ln2_b, b1, b2;
+  DenseW wqkv, wo, w1, w2;
+};
+
+struct LayerA {
+  float *x_in = nullptr, *x_mid = nullptr, *x_out = nullptr;
+  float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
+  bf16_t *h1 = nullptr, *a = nullptr, *h2 = nullptr, *pre = nullptr, *g = nullptr;
+  bf16_t* row[3] = {nullptr, nullptr, nullptr};
+  bf16_t* tr[3] = {nullptr, nullptr, nullptr};
+  float* lse2 = nullptr;
+};
+
+struct Stack {
+  const char* name = "";
+  int n = 0, feat = 0, featp = 0, d = 0, H = 0, dh = 0, dhp = 0, ff = 0, L = 0, NP = 0;
+  std::vector<LayerP> lp;
+  std::vector<LayerA> la;
+  // embedding (modal stacks only)
+  DenseW emb;
+  Tensor emb_b, pos;
+  bf16_t* xin16 = nullptr;  // [B*n][featp]
+  float* x0 = nullptr;      // stack input  [B*n][d]
+  float* out() { return L ? la[L - 1].x_out : x0; }
+};
+
+struct Bump {
+  char* base = nullptr;
+  size_t off = 0;
+  template <typename T>
+  T* take(size_t count) {
+    off = rups(off, 256);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+}  // namespace
+
+struct FactHandle {
+  FactConfig cfg;
+  int max_batch = 0;
+  bool training = false;
+  bool own_arenas = false;
+  size_t arena_floats = 0;
+  float *params = nullptr, *grads = nullptr, *adam_m = nullptr, *adam_v = nullptr;
+  std::vector<FactParamDesc> table;
+  Stack motion, audio, cross;
+  DenseW head;
+  Tensor head_b;
+  int outp = 0;  // out_dim padded to 32
+  char* shadow = nullptr;
+  size_t shadow_bytes = 0;
+  char* work = nullptr;
+  size_t work_bytes = 0;
+  // shared scratch
+  bf16_t* xf16 = nullptr;    // final hidden states bf16 [Mc][d]
+  float* pred = nullptr;     // [Mc][out_dim]
+  bf16_t* dpred = nullptr;   // [Mc][outp]
+  float* dx = nullptr;       // running residual gradient [Mc][d]
+  bf16_t* dx16 = nullptr;
+  float *dxm = nullptr, *dxa = nullptr;  // encoder gradients after the split
+  bf16_t *dxm16 = nullptr, *dxa16 = nullptr;
+  bf16_t* dh = nullptr;      // [Mc][d]
+  bf16_t* dpre = nullptr;    // [Mc][ffmax]
+  bf16_t* dqkv = nullptr;    // [Mc][3d]
+  bf16_t *dorow = nullptr, *dotr = nullptr;
+  float* dsum = nullptr;
+  bf16_t *tA = nullptr, *tB = nullptr;  // transposed operands for the non-tr wgrad path
+  float* scalars = nullptr;             // [16] device scalars (loss, sumsq)
+  bf16_t* ar_x16 = nullptr;             // AR: bf16 hidden rows of token 0 [B][d]
+  float* ar_motion = nullptr;           // AR: extended motion track (B, n_m + steps, F_m)
+  size_t ar_motion_floats = 0;
+  int64_t step = 0;
+  int wgrad_tr = 1;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// parameter table (Keras trainable_variables order: cross_modal_layer, motion_transformer,
+// motion_pos_embedding, motion_linear_embedding, audio_transformer, audio_pos_embedding,
+// audio_linear_embedding — attribute assignment order in fact_model.py:43-70)
+// ---------------------------------------------------------------------------------------------
+struct TableBuilder {
+  std::vector<FactParamDesc>* out;
+  size_t off = 0;
+  Tensor add(const std::string& name, int rows, int cols, int kind) {
+    off = rups(off, 64);
+    Tensor t;
+    t.off = off;
+    t.rows = rows;
+    t.cols = cols;
+    if (out) {
+      FactParamDesc d;
+      memset(&d, 0, sizeof(d));
+      snprintf(d.name, sizeof(d.name), "%s", name.c_str());
+      d.offset = off;
+      d.rows = rows;
+      d.cols = cols;
+      d.kind = kind;
+      out->push_back(d);
+    }
+    off += (size_t)rows * cols;
+    return t;
+  }
+};
+
+void build_stack_params(TableBuilder& tb, Stack& st, const std::string& prefix) {
+  st.lp.resize(st.L);
+  for (int l = 0; l < st.L; ++l) {
+    LayerP& p = st.lp[l];
+    const std::string b = prefix + "/layer_" + std::to_string(l);
+    p.ln1_g = tb.add(b + "/attn_norm/gamma", 1, st.d, 2);
+    p.ln1_b = tb.add(b + "/attn_norm/beta", 1, st.d, 3);
+    p.wqkv.w = tb.add(b + "/attn/to_qkv/kernel", st.d, 3 * st.d, 0);
+    p.wo.w = tb.add(b + "/attn/to_out/kernel", st.d, st.d, 0);
+    p.bo = tb.add(b + "/attn/to_out/bias", 1, st.d, 1);
+    p.ln2_g = tb.add(b + "/mlp_norm/gamma", 1, st.d, 2);
+    p.ln2_b = tb.add(b + "/mlp_norm/beta", 1, st.d, 3);
+    p.w1.w = tb.add(b + "/mlp/dense_1/kernel", st.d, st.ff, 0);
+    p.b1 = tb.add(b + "/mlp/dense_1/bias", 1, st.ff, 1);
+    p.w2.w = tb.add(b + "/mlp/dense_2/kernel", st.ff, st.d, 0);
+    p.b2 = tb.add(b + "/mlp/dense_2/bias", 1, st.d, 1);
+  }
+}
+
+void build_table(FactHandle* h, std::vector<FactParamDesc>* out, size_t* total) {
+  TableBuilder tb;
+  tb.out = out;
+  build_stack_params(tb, h->cross, "cross_modal_layer/transformer");
+  h->head.w = tb.add("cross_modal_layer/output/kernel", h->cross.d, h->cfg.out_dim, 0);
+  h->head_b = tb.add("cross_modal_layer/output/bias", 1, h->cfg.out_dim, 1);
+  build_stack_params(tb, h->motion, "motion_transformer");
+  h->motion.pos = tb.add("motion_pos_embedding/position_embedding", h->motion.n, h->motion.d, 4);
+  h->motion.emb.w = tb.add("motion_linear_embedding/kernel", h->motion.feat, h->motion.d, 0);
+  h->motion.emb_b = tb.add("motion_linear_embedding/bias", 1, h->motion.d, 1);
+  build_stack_params(tb, h->audio, "audio_transformer");
+  h->audio.pos = tb.add("audio_pos_embedding/position_embedding", h->audio.n, h->audio.d, 4);
+  h->audio.emb.w = tb.add("audio_linear_embedding/kernel", h->audio.feat, h->audio.d, 0);
+  h->audio.emb_b = tb.add("audio_linear_embedding/bias", 1, h->audio.d, 1);
+  *total = rups(tb.off, 64);
+}
+
+void init_stack_geo(Stack& st, const char* name, const FactStackCfg& c, int n, int feat) {
+  st.name = name;
+  st.n = n;
+  st.feat = feat;
+  st.featp = feat > 0 ? rup(feat, 32) : 0;
+  st.d = c.hidden;
+  st.H = c.heads;
+  st.dh = c.heads > 0 ? c.hidden / c.heads : 0;
+  st.dhp = rup(st.dh, 32);
+  st.ff = c.ff;
+  st.L = c.layers;
+  st.NP = rup(n, 128);
+}
+
+int validate(const FactConfig& c) {
+  const FactStackCfg* s[3] = {&c.motion, &c.audio, &c.cross};
+  for (int i = 0; i < 3; ++i) {
+    if (s[i]->hidden <= 0 || s[i]->heads <= 0 || s[i]->layers < 0 || s[i]->ff <= 0)
+      return fail(-1, "invalid stack hyper-parameters");
+    if (s[i]->hidden % s[i]->heads) return fail(-1, "hidden_size must be divisible by num_attention_heads");
+    const int dh = s[i]->hidden / s[i]->heads;
+    if (dh != 32 && dh != 64 && dh != 80 && dh != 128)
+      return fail(-3, "unsupported head dim " + std::to_string(dh) + " (supported: 32, 64, 80, 128)");
+    if (s[i]->hidden % 8 || s[i]->ff % 8) return fail(-1, "hidden/intermediate size must be multiples of 8");
+    if (s[i]->hidden > 2048) return fail(-1, "hidden_size > 2048 unsupported");
+  }
+  // base_models.py:184-189: ValueError when the two modal widths differ
+  if (c.motion.hidden != c.audio.hidden)
+    return fail(-2, "The modal_a hidden size (" + std::to_string(c.motion.hidden) +
+                        ") should be the same with the modal_b hidden size (" +
+                        std::to_string(c.audio.hidden) + ")");
+  if (c.cross.hidden != c.motion.hidden) return fail(-2, "cross-modal hidden size must equal the modal hidden size");
+  if (c.motion.seq_len <= 0 || c.audio.seq_len <= 0) return fail(-1, "sequence_length must be positive");
+  if (c.motion.seq_len % 8 || c.audio.seq_len % 8) return fail(-1, "sequence lengths must be multiples of 8");
+  if (c.motion.feature_dim <= 0 || c.audio.feature_dim <= 0) return fail(-1, "feature_dim must be positive");
+  if (c.out_dim <= 0) return fail(-1, "out_dim must be positive");
+  return 0;
+}
+
+void layout_dense(Bump& b, DenseW& w) {
+  w.lds = rup(w.w.cols, 32);
+  w.ldt = rup(w.w.rows, 32);
+  w.s = b.take<bf16_t>((size_t)w.w.rows * w.lds);
+  w.t = b.take<bf16_t>((size_t)w.w.cols * w.ldt);
+}
+
+void layout_shadow(FactHandle* h, Bump& b) {
+  Stack* sts[3] = {&h->cross, &h->motion, &h->audio};
+  for (Stack* st : sts) {
+    for (LayerP& p : st->lp) {
+      layout_dense(b, p.wqkv);
+      layout_dense(b, p.wo);
+      layout_dense(b, p.w1);
+      layout_dense(b, p.w2);
+    }
+  }
+  layout_dense(b, h->head);
+  layout_dense(b, h->motion.emb);
+  layout_dense(b, h->audio.emb);
+}
+
+void layout_stack_acts(FactHandle* h, Bump& b, Stack& st, int B) {
+  const size_t M = (size_t)B * st.n;
+  const size_t BH = (size_t)B * st.H;
+  const int nsets = h->training ? st.L : (st.L ? 1 : 0);
+  st.la.assign(st.L, LayerA());
+  if (st.feat > 0) st.xin16 = b.take<bf16_t>(M * st.featp);
+  st.x0 = b.take<float>(M * st.d);
+  std::vector<LayerA> sets(nsets);
+  for (int i = 0; i < nsets; ++i) {
+    LayerA& a = sets[i];
+    a.x_mid = b.take<float>(M * st.d);
+    a.mean1 = b.take<float>(M);
+    a.rstd1 = b.take<float>(M);
+    a.mean2 = b.take<float>(M);
+    a.rstd2 = b.take<float>(M);
+    a.h1 = b.take<bf16_t>(M * st.d);
+    a.a = b.take<bf16_t>(M * st.d);
+    a.h2 = b.take<bf16_t>(M * st.d);
+    a.pre = b.take<bf16_t>(M * st.ff);
+    a.g = b.take<bf16_t>(M * st.ff);
+    for (int w = 0; w < 3; ++w) {
+      a.row[w] = b.take<bf16_t>(BH * st.NP * st.dhp);
+      a.tr[w] = b.take<bf16_t>(BH * st.dh * st.NP);
+    }
+    a.lse2 = b.take<float>(BH * st.NP);
+  }
+  float* pp[2] = {nullptr, nullptr};
+  if (!h->training && st.L) {
+    pp[0] = b.take<float>(M * st.d);
+    pp[1] = b.take<float>(M * st.d);
+  }
+  for (int l = 0; l < st.L; ++l) {
+    LayerA a = sets[h->training ? l : 0];
+    a.x_in = (l == 0) ? st.x0 : st.la[l - 1].x_out;
+    a.x_out = h->training ? b.take<float>(M * st.d) : pp[l & 1];
+    st.la[l] = a;
+  }
+}
+
+void layout_work(FactHandle* h, Bump& b) {
+  const int B = h->max_batch;
+  layout_stack_acts(h, b, h->motion, B);
+  layout_stack_acts(h, b, h->audio, B);
+  layout_stack_acts(h, b, h->cross, B);
+  const int d = h->cross.d;
+  const size_t Mc = (size_t)B * h->cross.n;
+  const size_t Mm = (size_t)B * h->motion.n, Ma = (size_t)B * h->audio.n;
+  h->xf16 = b.take<bf16_t>(Mc * d);
+  h->pred = b.take<float>(Mc * h->cfg.out_dim);
+  h->scalars = b.take<float>(16);
+  h->ar_x16 = b.take<bf16_t>((size_t)B * d);
+  if (h->training) {
+    int ffmax = h->cross.ff;
+    if (h->motion.ff > ffmax) ffmax = h->motion.ff;
+    if (h->audio.ff > ffmax) ffmax = h->audio.ff;
+    int Hmax = h->cross.H, dhpmax = h->cross.dhp, NPmax = h->cross.NP;
+    size_t rowmax = 0, trmax = 0, lsemax = 0;
+    Stack* sts[3] = {&h->cross, &h->motion, &h->audio};
+    for (Stack* st : sts) {
+      const size_t BH = (size_t)B * st->H;
+      if (BH * st->NP * st->dhp > rowmax) rowmax = BH * st->NP * st->dhp;
+      if (BH * st->dh * st->NP > trmax) trmax = BH * st->dh * st->NP;
+      if (BH * st->NP > lsemax) lsemax = BH * st->NP;
+    }
+    (void)Hmax; (void)dhpmax; (void)NPmax;
+    h->dpred = b.take<bf16_t>(Mc * h->outp);
+    h->dx = b.take<float>(Mc * d);
+    h->dx16 = b.take<bf16_t>(Mc * d);
+    h->dxm = b.take<float>(Mm * d);
+    h->dxm16 = b.take<bf16_t>(Mm * d);
+    h->dxa = b.take<float>(Ma * d);
+    h->dxa16 = b.take<bf16_t>(Ma * d);
+    h->dh = b.take<bf16_t>(Mc * d);
+    h->dpre = b.take<bf16_t>(Mc * ffmax);
+    h->dqkv = b.take<bf16_t>(Mc * 3 * d);
+    h->dorow = b.take<bf16_t>(rowmax);
+    h->dotr = b.take<bf16_t>(trmax);
+    h->dsum = b.take<float>(lsemax);
+    const size_t wide = (size_t)(ffmax > 3 * d ? ffmax : 3 * d);
+    h->tA = b.take<bf16_t>(wide * rups(Mc, 8));
+    h->tB = b.take<bf16_t>(wide * rups(Mc, 8));
+  }
+}
+
+float* P(FactHandle* h, const Tensor& t) { return h->params + t.off; }
+float* G(FactHandle* h, const Tensor& t) { return h->grads + t.off; }
+
+int refresh_dense(FactHandle* h, DenseW& w, hipStream_t s) {
+  return launch_cast_transpose(P(h, w.w), w.w.rows, w.w.cols, w.s, w.lds, w.t, w.ldt, s);
+}
+
+int refresh_all(FactHandle* h, hipStream_t s) {
+  Stack* sts[3] = {&h->cross, &h->motion, &h->audio};
+  for (Stack* st : sts)
+    for (LayerP& p : st->lp) {
+      CHK(refresh_dense(h, p.wqkv, s));
+      CHK(refresh_dense(h, p.wo, s));
+      CHK(refresh_dense(h, p.w1, s));
+      CHK(refresh_dense(h, p.w2, s));
+    }
+  CHK(refresh_dense(h, h->head, s));
+  CHK(refresh_dense(h, h->motion.emb, s));
+  CHK(refresh_dense(h, h->audio.emb, s));
+  return 0;
+}
+
+GemmParams gp(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K) {
+  GemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.splitk = 1;
+  p.ep.alpha = 1.0f;
+  return p;
+}
+
+// dW[Mo][No] += A^T B ; A [K][Mo(lda)], B [K][No(ldb)]
+int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int ldb, int No, int K,
+          float* out, int ldo, hipStream_t s) {
+  const int tiles = ((Mo + 127) / 128) * ((No + 127) / 128);
+  const int ktiles = (K + 63) / 64;
+  int splitk = (768 + tiles - 1) / tiles;
+  if (splitk > ktiles / 4) splitk = ktiles / 4;
+  if (splitk < 1) splitk = 1;
+  if (h->wgrad_tr) {
+    GemmParams p = gp(A, lda, B, ldb, Mo, No, K);
+    p.splitk = splitk;
+    p.ep.out0 = out;
+    p.ep.ldo0 = ldo;
+    return launch_gemm_tn(EPI_ATOMIC_F32, p, s);
+  }
+  const int ldk = rup(K, 8);
+  CHK(launch_transpose_bf16(A, lda, K, Mo, h->tA, ldk, s));
+  CHK(launch_transpose_bf16(B, ldb, K, No, h->tB, ldk, s));
+  GemmParams p = gp(h->tA, ldk, h->tB, ldk, Mo, No, ldk);
+  p.splitk = splitk;
+  p.ep.out0 = out;
+  p.ep.ldo0 = ldo;
+  return launch_gemm_nt(EPI_ATOMIC_F32, p, s);
+}
+
+void heads_ep(EpiParams& ep, const Stack& st, bf16_t* const* row, bf16_t* const* tr, int nwhich) {
+  for (int w = 0; w < 3; ++w) {
+    ep.hrow[w] = (w < nwhich) ? row[w] : nullptr;
+    ep.htr[w] = (w < nwhich) ? tr[w] : nullptr;
+  }
+  ep.n_tok = st.n;
+  ep.n_pad = st.NP;
+  ep.heads = st.H;
+  ep.dh = st.dh;
+  ep.dhp = st.dhp;
+  ep.hid = st.d;
+}
+
+AttnParams attn_params(const Stack& st, const LayerA& a, int B) {
+  AttnParams ap;
+  memset(&ap, 0, sizeof(ap));
+  ap.qrow = a.row[0]; ap.krow = a.row[1]; ap.vrow = a.row[2];
+  ap.qtr = a.tr[0]; ap.ktr = a.tr[1]; ap.vtr = a.tr[2];
+  ap.out = a.a; ap.o = a.a; ap.lse2 = a.lse2;
+  ap.B = B; ap.H = st.H; ap.n = st.n; ap.NP = st.NP; ap.hid = st.d; ap.dh = st.dh;
+  ap.scale = 1.0f / sqrtf((float)st.d);  // dim**-0.5 with dim = hidden_size (base_models.py:66,104)
+  return ap;
+}
+
+int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
+  const int M = B * st.n, d = st.d;
+  LayerP& p = st.lp[l];
+  LayerA& a = st.la[l];
+  CHK(launch_ln_fwd(a.x_in, P(h, p.ln1_g), P(h, p.ln1_b), a.h1, a.mean1, a.rstd1, M, d, h->cfg.ln_eps, s));
+  {
+    GemmParams g = gp(a.h1, d, p.wqkv.t, p.wqkv.ldt, M, 3 * d, d);
+    heads_ep(g.ep, st, a.row, a.tr, 3);
+    CHK(launch_gemm_nt(EPI_HEADS, g, s));
+  }
+  CHK(launch_attn_fwd(attn_params(st, a, B), s));
+  {
+    GemmParams g = gp(a.a, d, p.wo.t, p.wo.ldt, M, d, d);
+    g.ep.out0 = a.x_mid; g.ep.ldo0 = d; g.ep.bias = P(h, p.bo); g.ep.resid = a.x_in; g.ep.ldr = d;
+    CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
+  }
+  CHK(launch_ln_fwd(a.x_mid, P(h, p.ln2_g), P(h, p.ln2_b), a.h2, a.mean2, a.rstd2, M, d, h->cfg.ln_eps, s));
+  {
+    GemmParams g = gp(a.h2, d, p.w1.t, p.w1.ldt, M, st.ff, d);
+    g.ep.out0 = a.pre; g.ep.ldo0 = st.ff; g.ep.out1 = a.g; g.ep.ldo1 = st.ff; g.ep.bias = P(h, p.b1);
+    CHK(launch_gemm_nt(EPI_BIAS_GELU, g, s));
+  }
+  {
+    GemmParams g = gp(a.g, st.ff, p.w2.t, p.w2.ldt, M, d, st.ff);
+    g.ep.out0 = a.x_out; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = a.x_mid; g.ep.ldr = d;
+    CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
+  }
+  return 0;
+}
+
+// On entry dx / dx16 hold dL/dx_out of layer l; on exit dL/dx_in.
+int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx16, hipStream_t s) {
+  const int M = B * st.n, d = st.d, ff = st.ff;
+  LayerP& p = st.lp[l];
+  LayerA& a = st.la[l];
+  // ---- MLP block: x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
+  CHK(wgrad(h, a.g, ff, ff, dx16, d, d, M, G(h, p.w2.w), d, s));
+  {
+    GemmParams g = gp(dx16, d, p.w2.s, p.w2.lds, M, ff, d);
+    g.ep.out0 = h->dpre; g.ep.ldo0 = ff; g.ep.pre = a.pre; g.ep.ldp = ff;
+    CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
+  }
+  CHK(wgrad(h, a.h2, d, d, h->dpre, ff, ff, M, G(h, p.w1.w), ff, s));
+  CHK(launch_colsum_bf16(h->dpre, ff, G(h, p.b1), M, ff, ff, s));
+  {
+    GemmParams g = gp(h->dpre, ff, p.w1.s, p.w1.lds, M, d, ff);
+    g.ep.out0 = h->dh; g.ep.ldo0 = d;
+    CHK(launch_gemm_nt(EPI_BF16, g, s));
+  }
+  CHK(launch_ln_bwd(h->dh, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, dx16, G(h, p.ln2_g),
+                    G(h, p.ln2_b), G(h, p.b2), M, d, s));
+  // ---- attention block: x_mid = x_in + Wo attn(Wqkv LN1(x_in)) + bo
+  CHK(wgrad(h, a.a, d, d, dx16, d, d, M, G(h, p.wo.w), d, s));
+  {
+    GemmParams g = gp(dx16, d, p.wo.s, p.wo.lds, M, d, d);
+    bf16_t* row[1] = {h->dorow};
+    bf16_t* tr[1] = {h->dotr};
+    heads_ep(g.ep, st, row, tr, 1);
+    CHK(launch_gemm_nt(EPI_HEADS, g, s));
+  }
+  {
+    AttnParams ap = attn_params(st, a, B);
+    ap.dorow = h->dorow; ap.dotr = h->dotr; ap.dsum = h->dsum; ap.dqkv = h->dqkv;
+    CHK(launch_attn_bwd(ap, s));
+  }
+  CHK(wgrad(h, a.h1, d, d, h->dqkv, 3 * d, 3 * d, M, G(h, p.wqkv.w), 3 * d, s));
+  {
+    GemmParams g = gp(h->dqkv, 3 * d, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
+    g.ep.out0 = h->dh; g.ep.ldo0 = d;
+    CHK(launch_gemm_nt(EPI_BF16, g, s));
+  }
+  CHK(launch_ln_bwd(h->dh, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, dx16, G(h, p.ln1_g),
+                    G(h, p.ln1_b), G(h, p.bo), M, d, s));
+  return 0;
+}
+
+// embed: x0 = in W + b + pos   (base_models.py:130-156)
+int embed_forward(FactHandle* h, Stack& st, const float* in, size_t batch_stride, int B, hipStream_t s) {
+  const int M = B * st.n;
+  CHK(launch_pad_cast(in, st.n, batch_stride, M, st.feat, st.xin16, st.featp, s));
+  GemmParams g = gp(st.xin16, st.featp, st.emb.t, st.emb.ldt, M, st.d, st.featp);
+  g.ep.out0 = st.x0; g.ep.ldo0 = st.d; g.ep.bias = P(h, st.emb_b); g.ep.pos = P(h, st.pos); g.ep.seq = st.n;
+  CHK(launch_gemm_nt(EPI_F32_BIAS_POS, g, s));
+  return 0;
+}
+
+int embed_backward(FactHandle* h, Stack& st, int B, float* dx, bf16_t* dx16, hipStream_t s) {
+  const int M = B * st.n;
+  CHK(wgrad(h, st.xin16, st.featp, st.feat, dx16, st.d, st.d, M, G(h, st.emb.w), st.d, s));
+  CHK(launch_colsum_f32(dx, st.d, G(h, st.emb_b), M, st.d, st.d, s));
+  CHK(launch_possum(dx, G(h, st.pos), B, st.n, st.d, s));
+  return 0;
+}
+
+int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height,
+           hipStream_t s) {
+  hipError_t e = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToDevice, s);
+  return e == hipSuccess ? 0 : -100;
+}
+
+// forward through both encoders and the cross-modal stack; final hidden states in cross.out()
+int model_forward_hidden(FactHandle* h, const float* motion, size_t m_stride, const float* audio,
+                         size_t a_stride, int B, hipStream_t s) {
+  Stack &mo = h->motion, &au = h->audio, &cr = h->cross;
+  CHK(embed_forward(h, mo, motion, m_stride, B, s));
+  for (int l = 0; l < mo.L; ++l) CHK(layer_forward(h, mo, l, B, s));
+  CHK(embed_forward(h, au, audio, a_stride, B, s));
+  for (int l = 0; l < au.L; ++l) CHK(layer_forward(h, au, l, B, s));
+  // tf.concat([motion, audio], axis=1)  (base_models.py:192-193)
+  const size_t rowb = (size_t)cr.d * sizeof(float);
+  CHK(copy2d(cr.x0, (size_t)cr.n * rowb, mo.out(), (size_t)mo.n * rowb, (size_t)mo.n * rowb, B, s));
+  CHK(copy2d(cr.x0 + (size_t)mo.n * cr.d, (size_t)cr.n * rowb, au.out(), (size_t)au.n * rowb,
+             (size_t)au.n * rowb, B, s));
+  for (int l = 0; l < cr.L; ++l) CHK(layer_forward(h, cr, l, B, s));
+  return 0;
+}
+
+int check_batch(FactHandle* h, int B) {
+  if (!h) return fail(-1, "null handle");
+  if (B <= 0 || B > h->max_batch)
+    return fail(-1, "batch " + std::to_string(B) + " outside (0, max_batch=" + std::to_string(h->max_batch) + "]");
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int fact_abi_version(void) { return FACT_ABI_VERSION; }
+const char* fact_last_error(void) { return g_err.c_str(); }
+
+static void init_geo(FactHandle* h, const FactConfig* cfg) {
+  h->cfg = *cfg;
+  if (h->cfg.ln_eps <= 0.f) h->cfg.ln_eps = 1e-5f;
+  init_stack_geo(h->motion, "motion", cfg->motion, cfg->motion.seq_len, cfg->motion.feature_dim);
+  init_stack_geo(h->audio, "audio", cfg->audio, cfg->audio.seq_len, cfg->audio.feature_dim);
+  init_stack_geo(h->cross, "cross", cfg->cross, cfg->motion.seq_len + cfg->audio.seq_len, 0);
+  h->outp = rup(cfg->out_dim, 32);
+}
+
+int fact_arena_size(const FactConfig* cfg, size_t* arena_floats, int* n_tensors) {
+  if (!cfg) return fail(-1, "null config");
+  int rc = validate(*cfg);
+  if (rc) return rc;
+  FactHandle tmp;
+  init_geo(&tmp, cfg);
+  std::vector<FactParamDesc> t;
+  size_t total = 0;
+  build_table(&tmp, &t, &total);
+  if (arena_floats) *arena_floats = total;
+  if (n_tensors) *n_tensors = (int)t.size();
+  return 0;
+}
+
+int fact_create(const FactConfig* cfg, int max_batch, int training, const FactArenas* arenas,
+                FactHandle** out) {
+  if (!cfg || !out) return fail(-1, "null argument");
+  if (max_batch <= 0) return fail(-1, "max_batch must be positive");
+  int rc = validate(*cfg);
+  if (rc) return rc;
+  FactHandle* h = new FactHandle();
+  init_geo(h, cfg);
+  h->max_batch = max_batch;
+  h->training = training != 0;
+  build_table(h, &h->table, &h->arena_floats);
+  const size_t abytes = h->arena_floats * sizeof(float);
+  if (arenas && arenas->params) {
+    h->params = arenas->params;
+    h->grads = arenas->grads;
+    h->adam_m = arenas->adam_m;
+    h->adam_v = arenas->adam_v;
+    if (h->training && (!h->grads || !h->adam_m || !h->adam_v)) {
+      delete h;
+      return fail(-1, "training handle needs grads/adam_m/adam_v arenas");
+    }
+  } else {
+    h->own_arenas = true;
+    HIPCHK(hipMalloc((void**)&h->params, abytes));
+    HIPCHK(hipMemset(h->params, 0, abytes));
+    if (h->training) {
+      HIPCHK(hipMalloc((void**)&h->grads, abytes));
+      HIPCHK(hipMalloc((void**)&h->adam_m, abytes));
+      HIPCHK(hipMalloc((void**)&h->adam_v, abytes));
+      HIPCHK(hipMemset(h->grads, 0, abytes));
+      HIPCHK(hipMemset(h->adam_m, 0, abytes));
+      HIPCHK(hipMemset(h->adam_v, 0, abytes));
+    }
+  }
+  {
+    Bump b;
+    layout_shadow(h, b);
+    h->shadow_bytes = rups(b.off, 256) + 256;
+    HIPCHK(hipMalloc((void**)&h->shadow, h->shadow_bytes));
+    HIPCHK(hipMemset(h->shadow, 0, h->shadow_bytes));
+    Bump b2;
+    b2.base = h->shadow;
+    layout_shadow(h, b2);
+  }
+  {
+    Bump b;
+    layout_work(h, b);
+    h->work_bytes = rups(b.off, 256) + 256;
+    HIPCHK(hipMalloc((void**)&h->work, h->work_bytes));
+    HIPCHK(hipMemset(h->work, 0, h->work_bytes));
+    Bump b2;
+    b2.base = h->work;
+    layout_work(h, b2);
+  }
+  *out = h;
+  return 0;
+}
+
+int fact_destroy(FactHandle* h) {
+  if (!h) return 0;
+  if (h->own_arenas) {
+    (void)hipFree(h->params);
+    (void)hipFree(h->grads);
+    (void)hipFree(h->adam_m);
+    (void)hipFree(h->adam_v);
+  }
+  (void)hipFree(h->shadow);
+  (void)hipFree(h->work);
+  (void)hipFree(h->ar_motion);
+  delete h;
+  return 0;
+}
+
+int fact_param_table(FactHandle* h, const FactParamDesc** table, int* n) {
+  if (!h) return fail(-1, "null handle");
+  if (table) *table = h->table.data();
+  if (n) *n = (int)h->table.size();
+  return 0;
+}
+
+int fact_arenas(FactHandle* h, FactArenas* out, size_t* arena_floats) {
+  if (!h) return fail(-1, "null handle");
+  if (out) {
+    out->params = h->params;
+    out->grads = h->grads;
+    out->adam_m = h->adam_m;
+    out->adam_v = h->adam_v;
+  }
+  if (arena_floats) *arena_floats = h->arena_floats;
+  return 0;
+}
+
+int fact_refresh_weights(FactHandle* h, void* stream) {
+  if (!h) return fail(-1, "null handle");
+  return refresh_all(h, (hipStream_t)stream);
+}
+
+int fact_set_option(FactHandle* h, const char* key, int value) {
+  if (!h || !key) return fail(-1, "null argument");
+  if (!strcmp(key, "wgrad_tr")) {
+    h->wgrad_tr = value;
+    return 0;
+  }
+  return fail(-1, std::string("unknown option ") + key);
+}
+
+static int head_forward(FactHandle* h, int B, float* out, hipStream_t s) {
+  Stack& cr = h->cross;
+  const int Mc = B * cr.n;
+  CHK(launch_cast_bf16(cr.out(), h->xf16, (size_t)Mc * cr.d, s));
+  GemmParams g = gp(h->xf16, cr.d, h->head.t, h->head.ldt, Mc, h->cfg.out_dim, cr.d);
+  g.ep.out0 = out; g.ep.ldo0 = h->cfg.out_dim; g.ep.bias = P(h, h->head_b);
+  CHK(launch_gemm_nt(EPI_F32_BIAS, g, s));
+  return 0;
+}
+
+int fact_forward(FactHandle* h, const float* motion, const float* audio, int B, float* out,
+                 void* stream) {
+  int rc = check_batch(h, B);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  CHK(model_forward_hidden(h, motion, (size_t)h->motion.n * h->motion.feat, audio,
+                           (size_t)h->audio.n * h->audio.feat, B, s));
+  return head_forward(h, B, out, s);
+}
+
+int fact_forward_backward(FactHandle* h, const float* motion, const float* audio,
+                          const float* target, int B, int T, float loss_scale, float* loss_out,
+                          void* stream) {
+  int rc = check_batch(h, B);
+  if (rc) return rc;
+  if (!h->training) return fail(-1, "handle was created with training=0");
+  Stack &mo = h->motion, &au = h->audio, &cr = h->cross;
+  if (T <= 0 || T > cr.n) return fail(-1, "target length outside (0, n_motion+n_audio]");
+  hipStream_t s = (hipStream_t)stream;
+  const int Mc = B * cr.n, d = cr.d, D = h->cfg.out_dim;
+  CHK(model_forward_hidden(h, motion, (size_t)mo.n * mo.feat, audio, (size_t)au.n * au.feat, B, s));
+  CHK(head_forward(h, B, h->pred, s));
+  // loss + dL/dpred
+  HIPCHK(hipMemsetAsync(h->scalars, 0, 16 * sizeof(float), s));
+  CHK(launch_mse_loss(h->pred, target, h->scalars, h->dpred, B, cr.n, T, D, h->outp, loss_scale, s));
+  if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, h->scalars, sizeof(float), hipMemcpyDeviceToDevice, s));
+  // head backward
+  CHK(wgrad(h, h->xf16, d, d, h->dpred, h->outp, D, Mc, G(h, h->head.w), D, s));
+  CHK(launch_colsum_bf16(h->dpred, h->outp, G(h, h->head_b), Mc, h->outp, D, s));
+  {
+    GemmParams g = gp(h->dpred, h->outp, h->head.s, h->head.lds, Mc, d, h->outp);
+    g.ep.out0 = h->dx; g.ep.ldo0 = d; g.ep.out1 = h->dx16; g.ep.ldo1 = d;
+    CHK(launch_gemm_nt(EPI_F32_BF16, g, s));
+  }
+  for (int l = cr.L - 1; l >= 0; --l) CHK(layer_backward(h, cr, l, B, h->dx, h->dx16, s));
+  CHK(launch_split_grad(h->dx, B, mo.n, au.n, d, h->dxm, h->dxm16, h->dxa, h->dxa16, s));
+  for (int l = au.L - 1; l >= 0; --l) CHK(layer_backward(h, au, l, B, h->dxa, h->dxa16, s));
+  CHK(embed_backward(h, au, B, h->dxa, h->dxa16, s));
+  for (int l = mo.L - 1; l >= 0; --l) CHK(layer_backward(h, mo, l, B, h->dxm, h->dxm16, s));
+  CHK(embed_backward(h, mo, B, h->dxm, h->dxm16, s));
+  return 0;
+}
+
+int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps, float clip_norm,
+                   void* stream) {
+  if (!h) return fail(-1, "null handle");
+  if (!h->training) return fail(-1, "handle was created with training=0");
+  hipStream_t s = (hipStream_t)stream;
+  float gscale = 1.0f;
+  if (clip_norm > 0.f) {
+    // tf.clip_by_global_norm (single_task_trainer.py:180-183)
+    HIPCHK(hipMemsetAsync(h->scalars + 8, 0, sizeof(float), s));
+    CHK(launch_sumsq(h->grads, h->arena_floats, h->scalars + 8, s));
+    float ss = 0.f;
+    HIPCHK(hipMemcpyAsync(&ss, h->scalars + 8, sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const float norm = sqrtf(ss);
+    gscale = clip_norm / fmaxf(norm, clip_norm);
+  }
+  h->step += 1;
+  const double t = (double)h->step;
+  const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t));
+  CHK(launch_adam(h->params, h->adam_m, h->adam_v, h->grads, h->arena_floats, (float)lr_t, beta1, beta2,
+                  eps, gscale, s));
+  return refresh_all(h, s);
+}
+
+int fact_get_step(FactHandle* h, int64_t* step) {
+  if (!h || !step) return fail(-1, "null argument");
+  *step = h->step;
+  return 0;
+}
+int fact_set_step(FactHandle* h, int64_t step) {
+  if (!h) return fail(-1, "null handle");
+  h->step = step;
+  return 0;
+}
+
+int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, int B, int audio_len,
+                  int steps, float* out, int* steps_done, void* stream) {
+  int rc = check_batch(h, B);
+  if (rc) return rc;
+  Stack &mo = h->motion, &au = h->audio, &cr = h->cross;
+  if (h->cfg.out_dim != mo.feat) return fail(-1, "auto-regressive inference needs out_dim == motion feature_dim");
+  if (steps < 0) return fail(-1, "steps must be >= 0");
+  hipStream_t s = (hipStream_t)stream;
+  // fact_model.py:124-126: stop when the audio window runs short
+  int nsteps = audio_len - au.n + 1;
+  if (nsteps > steps) nsteps = steps;
+  if (nsteps < 0) nsteps = 0;
+  if (steps_done) *steps_done = nsteps;
+  if (nsteps == 0) return 0;
+  const int F = mo.feat;
+  const size_t ext = (size_t)(mo.n + nsteps) * F;  // per-sample floats of the extended motion track
+  if (h->ar_motion_floats < ext * B) {
+    (void)hipFree(h->ar_motion);
+    h->ar_motion = nullptr;
+    HIPCHK(hipMalloc((void**)&h->ar_motion, ext * B * sizeof(float)));
+    h->ar_motion_floats = ext * B;
+  }
+  CHK(copy2d(h->ar_motion, ext * sizeof(float), motion_seed, (size_t)mo.n * F * sizeof(float),
+             (size_t)mo.n * F * sizeof(float), B, s));
+  for (int i = 0; i < nsteps; ++i) {
+    // motion window = frames [i, i+n_m) of the extended track; audio window = frames [i, i+n_a)
+    CHK(model_forward_hidden(h, h->ar_motion + (size_t)i * F, ext, audio + (size_t)i * au.feat,
+                             (size_t)audio_len * au.feat, B, s));
+    // output[:, 0:1, :] only (fact_model.py:128): head on token 0 of every sample
+    CHK(launch_pad_cast(cr.out(), 1, (size_t)cr.n * cr.d, B, cr.d, h->ar_x16, cr.d, s));
+    GemmParams g = gp(h->ar_x16, cr.d, h->head.t, h->head.ldt, B, h->cfg.out_dim, cr.d);
+    g.ep.out0 = h->ar_motion + (size_t)(mo.n + i) * F; g.ep.ldo0 = (int)ext; g.ep.bias = P(h, h->head_b);
+    CHK(launch_gemm_nt(EPI_F32_BIAS, g, s));
+  }
+  CHK(copy2d(out, (size_t)steps * F * sizeof(float), h->ar_motion + (size_t)mo.n * F, ext * sizeof(float),
+             (size_t)nsteps * F * sizeof(float), B, s));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// single-op entry points
+// ---------------------------------------------------------------------------------------------
+int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                    void* out0, int ldo0, void* out1, int ldo1, const float* bias, const float* pos,
+                    int seq, const float* resid, int ldr, const void* pre, int ldp, void* stream) {
+  if (epi == EPI_HEADS) return fail(-1, "use fact_op_attention for the heads epilogue");
+  GemmParams g = gp((const bf16_t*)A, lda, (const bf16_t*)B, ldb, M, N, K);
+  g.ep.out0 = out0; g.ep.ldo0 = ldo0; g.ep.out1 = out1; g.ep.ldo1 = ldo1;
+  g.ep.bias = bias; g.ep.pos = pos; g.ep.seq = seq; g.ep.resid = resid; g.ep.ldr = ldr;
+  g.ep.pre = (const bf16_t*)pre; g.ep.ldp = ldp;
+  CHK(launch_gemm_nt(epi, g, (hipStream_t)stream));
+  return 0;
+}
+
+int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int No, int K,
+                    float* out, int ldo, int splitk, int use_tr, void* scratch, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (use_tr) {
+    GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)B, ldb, Mo, No, K);
+    p.splitk = splitk; p.ep.out0 = out; p.ep.ldo0 = ldo;
+    CHK(launch_gemm_tn(EPI_ATOMIC_F32, p, s));
+    return 0;
+  }
+  if (!scratch) return fail(-1, "scratch required for the transpose path");
+  const int ldk = rup(K, 8);
+  bf16_t* tA = (bf16_t*)scratch;
+  bf16_t* tB = tA + (size_t)rup(Mo, 8) * ldk;
+  HIPCHK(hipMemsetAsync(scratch, 0, ((size_t)rup(Mo, 8) + rup(No, 8)) * ldk * sizeof(bf16_t), s));
+  CHK(launch_transpose_bf16((const bf16_t*)A, lda, K, Mo, tA, ldk, s));
+  CHK(launch_transpose_bf16((const bf16_t*)B, ldb, K, No, tB, ldk, s));
+  GemmParams p = gp(tA, ldk, tB, ldk, Mo, No, ldk);
+  p.splitk = splitk; p.ep.out0 = out; p.ep.ldo0 = ldo;
+  CHK(launch_gemm_nt(EPI_ATOMIC_F32, p, s));
+  return 0;
+}
+
+int fact_op_ln_fwd(const float* x, const float* gamma, const float* beta, void* hh, float* mean,
+                   float* rstd, int M, int C, float eps, void* stream) {
+  CHK(launch_ln_fwd(x, gamma, beta, (bf16_t*)hh, mean, rstd, M, C, eps, (hipStream_t)stream));
+  return 0;
+}
+
+int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
+                   const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
+                   float* dbeta, float* dbias_prev, int M, int C, void* stream) {
+  CHK(launch_ln_bwd((const bf16_t*)dh, x, mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, dgamma, dbeta,
+                    dbias_prev, M, C, (hipStream_t)stream));
+  return 0;
+}
+
+namespace {
+struct AttnScratch {
+  size_t row[4], tr[4], lse, dsum, total;
+};
+AttnScratch attn_scratch_layout(int B, int H, int n, int dh) {
+  AttnScratch a;
+  const size_t BH = (size_t)B * H, NP = rup(n, 128), dhp = rup(dh, 32);
+  size_t off = 0;
+  for (int i = 0; i < 4; ++i) { a.row[i] = off; off += rups(BH * NP * dhp * 2, 256); }
+  for (int i = 0; i < 4; ++i) { a.tr[i] = off; off += rups(BH * dh * NP * 2, 256); }
+  a.lse = off; off += rups(BH * NP * 4, 256);
+  a.dsum = off; off += rups(BH * NP * 4, 256);
+  a.total = off;
+  return a;
+}
+}  // namespace
+
+size_t fact_op_attention_scratch(int B, int H, int n, int dh) {
+  return attn_scratch_layout(B, H, n, dh).total;
+}
+
+// Test driver for the attention kernels: splits a packed (qkv h d) bf16 tensor into the per-head
+// operand buffers with the same EPI_HEADS epilogue the model uses (GEMM against an identity).
+int fact_op_attention(const void* qkv, int B, int H, int n, int dh, float scale, void* out,
+                      const void* dout, void* dqkv, void* scratch, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int hid = H * dh, M = B * n;
+  if (n % 8) return fail(-1, "n must be a multiple of 8");
+  AttnScratch L = attn_scratch_layout(B, H, n, dh);
+  char* sc = (char*)scratch;
+  HIPCHK(hipMemsetAsync(sc, 0, L.total, s));
+  Stack st;
+  st.n = n; st.d = hid; st.H = H; st.dh = dh; st.dhp = rup(dh, 32); st.NP = rup(n, 128);
+  // identity [3*hid][3*hid] bf16 as the B operand
+  bf16_t* eye = nullptr;
+  const int W = 3 * hid;
+  HIPCHK(hipMalloc((void**)&eye, (size_t)W * W * sizeof(bf16_t)));
+  {
+    std::vector<uint16_t> he((size_t)W * W, 0);
+    for (int i = 0; i < W; ++i) he[(size_t)i * W + i] = 0x3F80;  // bf16 1.0
+    HIPCHK(hipMemcpyAsync(eye, he.data(), he.size() * 2, hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+  }
+  bf16_t* row[4];
+  bf16_t* tr[4];
+  for (int i = 0; i < 4; ++i) { row[i] = (bf16_t*)(sc + L.row[i]); tr[i] = (bf16_t*)(sc + L.tr[i]); }
+  {
+    GemmParams g = gp((const bf16_t*)qkv, W, eye, W, M, W, W);
+    heads_ep(g.ep, st, row, tr, 3);
+    int rc = launch_gemm_nt(EPI_HEADS, g, s);
+    if (rc) { (void)hipFree(eye); return fail(rc, "heads gemm failed"); }
+  }
+  AttnParams ap;
+  memset(&ap, 0, sizeof(ap));
+  ap.qrow = row[0]; ap.krow = row[1]; ap.vrow = row[2];
+  ap.qtr = tr[0]; ap.ktr = tr[1]; ap.vtr = tr[2];
+  ap.out = (bf16_t*)out; ap.o = (const bf16_t*)out; ap.lse2 = (float*)(sc + L.lse);
+  ap.B = B; ap.H = H; ap.n = n; ap.NP = st.NP; ap.hid = hid; ap.dh = dh; ap.scale = scale;
+  int rc = launch_attn_fwd(ap, s);
+  if (rc == 0 && dout) {
+    GemmParams g = gp((const bf16_t*)dout, hid, eye, W, M, hid, hid);
+    bf16_t* r1[1] = {row[3]};
+    bf16_t* t1[1] = {tr[3]};
+    heads_ep(g.ep, st, r1, t1, 1);
+    rc = launch_gemm_nt(EPI_HEADS, g, s);
+    if (rc == 0) {
+      ap.dorow = row[3]; ap.dotr = tr[3]; ap.dsum = (float*)(sc + L.dsum); ap.dqkv = (bf16_t*)dqkv;
+      rc = launch_attn_bwd(ap, s);
+    }
+  }
+  (void)hipStreamSynchronize(s);
+  (void)hipFree(eye);
+  if (rc) return fail(rc, "attention launch failed");
+  return 0;
+}
+
+int fact_op_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, float b1, float b2,
+                 float eps, void* stream) {
+  CHK(launch_adam(p, m, v, g, n, lr_t, b1, b2, eps, 1.0f, (hipStream_t)stream));
+  return 0;
+}
+
+int fact_op_mse(const float* pred, const float* target, float* loss, void* dpred, int B, int n, int T,
+                int D, int ldp, float gscale, void* stream) {
+  CHK(launch_mse_loss(pred, target, loss, (bf16_t*)dpred, B, n, T, D, ldp, gscale, (hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// bf16 MFMA GEMM engine for gfx950: C[M][N] = sum_k A(m,k) * B(n,k), fp32 accumulate,
+// pluggable fused epilogues.  Two operand-layout families:
+//   NT : A[m*lda + k], B[n*ldb + k]            (both contraction-contiguous)   fwd / dgrad
+//   TN : A[k*lda + m], B[k*ldb + n]            (both contraction-strided)      wgrad
+// The TN kernel stages [k][m] tiles in LDS and builds MFMA fragments with the gfx950 LDS
+// transpose read (ds_read_b64_tr_b16), so no transposed activation copies ever hit HBM.
+#pragma once
+#include "common.h"
+
+enum EpiKind : int {
+  EPI_BF16 = 0,           // out0 bf16 = acc
+  EPI_F32_BIAS = 1,       // out0 f32  = acc + bias[n]
+  EPI_F32_BIAS_POS = 2,   // out0 f32  = acc + bias[n] + pos[m % seq][n]
+  EPI_F32_BIAS_RESID = 3, // out0 f32  = acc + bias[n] + resid[m][n]
+  EPI_BIAS_GELU = 4,      // out0 bf16 = acc + bias[n] (pre-activation), out1 bf16 = gelu(pre)
+  EPI_GELU_BWD = 5,       // out0 bf16 = acc * gelu'(pre[m][n])
+  EPI_HEADS = 6,          // scatter to per-head row-major and transposed q/k/v style buffers
+  EPI_ATOMIC_F32 = 7,     // atomicAdd(out0 f32, alpha * acc)   (split-K wgrad)
+  EPI_F32_BF16 = 8,       // out0 f32 = acc, out1 bf16 = acc
+};
+
+struct EpiParams {
+  void* out0;
+  int ldo0;
+  void* out1;
+  int ldo1;
+  const float* bias;
+  const float* pos;
+  int seq;
+  const float* resid;
+  int ldr;
+  const bf16_t* pre;
+  int ldp;
+  // EPI_HEADS: column c -> (which = c / hid, h = (c % hid) / dh, d = c % dh); row -> (b, t)
+  bf16_t* hrow[3];  // [B*H][n_pad][dhp]
+  bf16_t* htr[3];   // [B*H][dh][n_pad]
+  int n_tok, n_pad, heads, dh, dhp, hid;
+  float alpha;
+};
+
+struct GemmParams {
+  const bf16_t* A;
+  int lda;
+  const bf16_t* B;
+  int ldb;
+  int M, N, K;
+  int splitk;
+  EpiParams ep;
+};
+
+// Launchers. Return 0 on success, negative on invalid arguments.
+int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);
+int launch_gemm_tn(int epi, const GemmParams& p, hipStream_t stream);

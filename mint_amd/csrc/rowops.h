@@ -1,0 +1,52 @@
+// HBM-bound row/elementwise kernels of the FACT train step (gfx950).
+#pragma once
+#include "common.h"
+
+// LayerNorm forward (eps inside the rsqrt, biased variance; mint/core/base_models.py:27).
+// x f32 [M][C] -> h bf16 [M][C]; saves mean/rstd f32 [M].  C % 4 == 0, C <= 2048.
+int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t* h, float* mean,
+                  float* rstd, int M, int C, float eps, hipStream_t s);
+
+// LayerNorm backward fused with the residual-gradient add:
+//   dx = dres + LNbwd(dh);  dgamma += sum_rows dh*xhat;  dbeta += sum_rows dh;
+//   dbias_prev += sum_rows dres (bias gradient of the GEMM whose output fed this residual add).
+// dx may alias dres.  dx_bf16 / dbias_prev / dres may be null.
+int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const float* rstd,
+                  const float* gamma, const float* dres, float* dx, bf16_t* dx_bf16, float* dgamma,
+                  float* dbeta, float* dbias_prev, int M, int C, hipStream_t s);
+
+// out[c] += sum_m in[m][c]   (bf16 or f32 input), C % 8 == 0 for bf16, % 4 for f32
+// only columns < Cout are accumulated into out
+int launch_colsum_bf16(const bf16_t* in, int ld, float* out, int M, int C, int Cout, hipStream_t s);
+int launch_colsum_f32(const float* in, int ld, float* out, int M, int C, int Cout, hipStream_t s);
+
+// dpos[t][c] += sum_b dx[b][t][c]
+int launch_possum(const float* dx, float* dpos, int B, int n, int C, hipStream_t s);
+
+// MSE loss on the first T tokens (mint/core/fact_model.py:143-148):
+//   loss_sum[0] += sum((target - pred[:, :T])^2) / (B*T*D)
+//   dpred bf16 [B*n][ldp] = gscale * 2*(pred-target)/(B*T*D) on rows t<T, else 0 (pads too)
+int launch_mse_loss(const float* pred, const float* target, float* loss_sum, bf16_t* dpred, int B,
+                    int n, int T, int D, int ldp, float gscale, hipStream_t s);
+
+// Keras Adam (epsilon outside the bias correction), fused with gradient zeroing:
+//   m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr_t * m / (sqrt(v) + eps); g = 0
+int launch_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, float b1, float b2,
+                float eps, float gscale, hipStream_t s);
+
+// f32 [R][C] -> bf16 dst [R][ldd] and bf16 dstT [C][ldt] (either may be null)
+int launch_cast_transpose(const float* src, int R, int C, bf16_t* dst, int ldd, bf16_t* dstT, int ldt,
+                          hipStream_t s);
+// bf16 [R][C] (ld) -> bf16 [C][R] (ldt)
+int launch_transpose_bf16(const bf16_t* src, int ld, int R, int C, bf16_t* dstT, int ldt,
+                          hipStream_t s);
+// f32 rows (b, t) at src + b*batch_stride + t*F (M = B*n rows) -> bf16 [M][Fp] zero-padded
+int launch_pad_cast(const float* src, int n, size_t batch_stride, int M, int F, bf16_t* dst, int Fp,
+                    hipStream_t s);
+// f32 -> bf16 flat
+int launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
+// split the cross-modal gradient (B, na+nb, C) into the two encoder gradients (f32 + bf16 copies)
+int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, bf16_t* da16,
+                      float* db, bf16_t* db16, hipStream_t s);
+// sum of squares of a flat f32 buffer -> out[0] (atomicAdd), and flat scale
+int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s);

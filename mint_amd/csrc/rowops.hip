@@ -1,0 +1,457 @@
+// HBM-bound row/elementwise kernels (see rowops.h).  One wave (64 lanes) per token row for the
+// LayerNorm kernels: float4 loads, wave-shuffle reductions, no LDS in the row statistics.
+#include "rowops.h"
+
+namespace {
+
+constexpr int LN_MAXV = 8;  // float4 vectors per lane -> C <= 2048
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta,
+                                                     bf16_t* __restrict__ h, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = C >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
+  float4 v[LN_MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      v[i] = xr[idx];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0) {
+    mean[row] = mu;
+    rstd[row] = rs;
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+  bf16x4* hr = reinterpret_cast<bf16x4*>(h + (size_t)row * C);
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float4 g = g4[idx], b = b4[idx];
+      bf16x4 o = {(bf16_t)((v[i].x - mu) * rs * g.x + b.x), (bf16_t)((v[i].y - mu) * rs * g.y + b.y),
+                  (bf16_t)((v[i].z - mu) * rs * g.z + b.z), (bf16_t)((v[i].w - mu) * rs * g.w + b.w)};
+      hr[idx] = o;
+    }
+  }
+}
+
+// Each block handles LN_BWD_ROWS rows (4 waves x LN_BWD_ROWS/4 rows); per-lane column partials
+// of dgamma/dbeta/dbias are reduced across the 4 waves in LDS, then one atomicAdd per column.
+constexpr int LN_BWD_ROWS = 32;
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const bf16_t* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* dres, float* dx,
+    bf16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ dbias_prev, int M, int C) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [3][4 waves][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = C >> 2;
+  const float invC = 1.0f / (float)C;
+  float4 ag[MAXV], ab[MAXV], ar[MAXV], gm[MAXV];
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[i] = ag[i];
+    ar[i] = ag[i];
+    const int idx = lane + i * 64;
+    gm[i] = (idx < nv) ? g4[idx] : ag[i];
+  }
+  const int row_beg = blockIdx.x * LN_BWD_ROWS;
+  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+    const int row = row_beg + rr;
+    if (row >= M) break;
+    const float mu = mean[row], rs = rstd[row];
+    const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
+    const bf16x4* dhr = reinterpret_cast<const bf16x4*>(dh + (size_t)row * C);
+    float4 xh[MAXV], dy[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int idx = lane + i * 64;
+      if (idx < nv) {
+        const float4 xv = xr[idx];
+        const bf16x4 d = dhr[idx];
+        const float d0 = (float)d[0], d1 = (float)d[1], d2 = (float)d[2], d3 = (float)d[3];
+        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        dy[i] = make_float4(d0 * gm[i].x, d1 * gm[i].y, d2 * gm[i].z, d3 * gm[i].w);
+        s1 += (dy[i].x + dy[i].y) + (dy[i].z + dy[i].w);
+        s2 += (dy[i].x * xh[i].x + dy[i].y * xh[i].y) + (dy[i].z * xh[i].z + dy[i].w * xh[i].w);
+        ag[i].x += d0 * xh[i].x; ag[i].y += d1 * xh[i].y; ag[i].z += d2 * xh[i].z; ag[i].w += d3 * xh[i].w;
+        ab[i].x += d0; ab[i].y += d1; ab[i].z += d2; ab[i].w += d3;
+      }
+    }
+    s1 = wave_sum(s1) * invC;
+    s2 = wave_sum(s2) * invC;
+    const float4* rr4 = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * C) : nullptr;
+    float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * C);
+    bf16x4* dx16r = dx16 ? reinterpret_cast<bf16x4*>(dx16 + (size_t)row * C) : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int idx = lane + i * 64;
+      if (idx < nv) {
+        float4 o = make_float4(rs * (dy[i].x - s1 - xh[i].x * s2), rs * (dy[i].y - s1 - xh[i].y * s2),
+                               rs * (dy[i].z - s1 - xh[i].z * s2), rs * (dy[i].w - s1 - xh[i].w * s2));
+        if (rr4) {
+          const float4 r = rr4[idx];
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+          ar[i].x += r.x; ar[i].y += r.y; ar[i].z += r.z; ar[i].w += r.w;
+        }
+        dxr[idx] = o;
+        if (dx16r) {
+          bf16x4 o16 = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+          dx16r[idx] = o16;
+        }
+      }
+    }
+  }
+  // cross-wave reduction
+  float4* r4 = reinterpret_cast<float4*>(red);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      r4[(0 * 4 + wave) * nv + idx] = ag[i];
+      r4[(1 * 4 + wave) * nv + idx] = ab[i];
+      r4[(2 * 4 + wave) * nv + idx] = ar[i];
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f, r = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      a += red[(0 * 4 + w) * C + c];
+      b += red[(1 * 4 + w) * C + c];
+      r += red[(2 * 4 + w) * C + c];
+    }
+    atomicAdd(dgamma + c, a);
+    atomicAdd(dbeta + c, b);
+    if (dbias_prev && dres) atomicAdd(dbias_prev + c, r);
+  }
+}
+
+// column sums: block = 32 column-chunks x 8 row lanes; each thread owns VEC columns
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, int ld,
+                                                     float* __restrict__ out, int M, int C,
+                                                     int Cout, int rows_per_block) {
+  __shared__ float red[8][32 * VEC + 1];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c0 = (blockIdx.x * 32 + cx) * VEC;
+  const int r_beg = blockIdx.y * rows_per_block;
+  const int r_end = min(M, r_beg + rows_per_block);
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (c0 < C) {
+    for (int r = r_beg + ry; r < r_end; r += 8) {
+      const T* p = in + (size_t)r * ld + c0;
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += (float)v[j];
+      } else {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[ry][cx * VEC + j] = acc[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < 32 * VEC; c += 256) {
+    const int gc = blockIdx.x * 32 * VEC + c;
+    if (gc < Cout) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += red[w][c];
+      atomicAdd(out + gc, s);
+    }
+  }
+}
+
+__global__ void possum_kernel(const float* __restrict__ dx, float* __restrict__ dpos, int B,
+                              size_t nC) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nC) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += dx[(size_t)b * nC + i];
+  dpos[i] += s;
+}
+
+__global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__ pred,
+                                                       const float* __restrict__ target,
+                                                       float* __restrict__ loss_sum,
+                                                       bf16_t* __restrict__ dpred, int B, int n, int T,
+                                                       int D, int ldp, float inv_count, float gscale) {
+  // one block per (b, t) row of dpred
+  const int row = blockIdx.x;
+  const int b = row / n, t = row - b * n;
+  float part = 0.f;
+  for (int c = threadIdx.x; c < ldp; c += blockDim.x) {
+    float g = 0.f;
+    if (t < T && c < D) {
+      const float diff = pred[(size_t)row * D + c] - target[((size_t)b * T + t) * D + c];
+      part += diff * diff;
+      g = 2.0f * diff * inv_count * gscale;
+    }
+    dpred[(size_t)row * ldp + c] = (bf16_t)g;
+  }
+  if (t < T) {
+    __shared__ float red[4];
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float s = 0.f;
+      for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += red[w];
+      atomicAdd(loss_sum, s * inv_count);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, float4* __restrict__ m,
+                                                   float4* __restrict__ v, float4* __restrict__ g,
+                                                   size_t n4, float lr_t, float b1, float b2, float eps,
+                                                   float gscale) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 gv = g[i], mv = m[i], vv = v[i], pv = p[i];
+    gv.x *= gscale; gv.y *= gscale; gv.z *= gscale; gv.w *= gscale;
+    mv.x = b1 * mv.x + (1.f - b1) * gv.x; mv.y = b1 * mv.y + (1.f - b1) * gv.y;
+    mv.z = b1 * mv.z + (1.f - b1) * gv.z; mv.w = b1 * mv.w + (1.f - b1) * gv.w;
+    vv.x = b2 * vv.x + (1.f - b2) * gv.x * gv.x; vv.y = b2 * vv.y + (1.f - b2) * gv.y * gv.y;
+    vv.z = b2 * vv.z + (1.f - b2) * gv.z * gv.z; vv.w = b2 * vv.w + (1.f - b2) * gv.w * gv.w;
+    pv.x -= lr_t * mv.x / (sqrtf(vv.x) + eps); pv.y -= lr_t * mv.y / (sqrtf(vv.y) + eps);
+    pv.z -= lr_t * mv.z / (sqrtf(vv.z) + eps); pv.w -= lr_t * mv.w / (sqrtf(vv.w) + eps);
+    p[i] = pv; m[i] = mv; v[i] = vv; g[i] = z;
+  }
+}
+
+// 64x64 tile cast/transpose through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const T* __restrict__ src, int lds_,
+                                                             int R, int C, bf16_t* __restrict__ dst,
+                                                             int ldd, bf16_t* __restrict__ dstT,
+                                                             int ldt) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) {
+      v = (float)src[(size_t)r * lds_ + c];
+      if (dst) dst[(size_t)r * ldd + c] = (bf16_t)v;
+    }
+    tile[rr][tx] = v;
+  }
+  if (!dstT) return;
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, r = r0 + tx;
+    if (c < C && r < R) dstT[(size_t)c * ldt + r] = (bf16_t)tile[tx][cc];
+  }
+}
+
+__global__ void pad_cast_kernel(const float* __restrict__ src, int n, size_t batch_stride, int M,
+                                int F, bf16_t* __restrict__ dst, int Fp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * Fp) return;
+  const int r = (int)(i / Fp), c = (int)(i - (size_t)r * Fp);
+  const int b = r / n, t = r - b * n;
+  dst[i] = (c < F) ? (bf16_t)src[(size_t)b * batch_stride + (size_t)t * F + c] : (bf16_t)0.f;
+}
+
+__global__ void cast_bf16_kernel(const float4* __restrict__ src, bf16x4* __restrict__ dst, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = src[i];
+    bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+    dst[i] = o;
+  }
+}
+
+__global__ void split_grad_kernel(const float4* __restrict__ dx, int B, int na, int nb, int C4,
+                                  float4* __restrict__ da, bf16x4* __restrict__ da16,
+                                  float4* __restrict__ db, bf16x4* __restrict__ db16) {
+  const size_t total = (size_t)B * (na + nb) * C4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t row = i / C4;
+    const int c = (int)(i - row * C4);
+    const int b = (int)(row / (na + nb));
+    const int t = (int)(row - (size_t)b * (na + nb));
+    const float4 v = dx[i];
+    bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+    if (t < na) {
+      const size_t j = ((size_t)b * na + t) * C4 + c;
+      da[j] = v;
+      da16[j] = o;
+    } else {
+      const size_t j = ((size_t)b * nb + (t - na)) * C4 + c;
+      db[j] = v;
+      db16[j] = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float4* __restrict__ g, size_t n4,
+                                                    float* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const float4 v = g[i];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+inline int grid_for(size_t n, int block, int cap = 4096) {
+  size_t g = (n + block - 1) / block;
+  if (g > (size_t)cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace
+
+int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t* h, float* mean,
+                  float* rstd, int M, int C, float eps, hipStream_t s) {
+  if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0) return -1;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd,
+                     M, C, eps);
+  return 0;
+}
+
+int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const float* rstd,
+                  const float* gamma, const float* dres, float* dx, bf16_t* dx_bf16, float* dgamma,
+                  float* dbeta, float* dbias_prev, int M, int C, hipStream_t s) {
+  if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0) return -1;
+  const int grid = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+  const size_t shmem = (size_t)3 * 4 * C * sizeof(float);
+  if (C <= 1024) {
+    hipLaunchKernelGGL((ln_bwd_kernel<4>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
+                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, M, C);
+  } else {
+    hipLaunchKernelGGL((ln_bwd_kernel<8>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
+                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, M, C);
+  }
+  return 0;
+}
+
+int launch_colsum_bf16(const bf16_t* in, int ld, float* out, int M, int C, int Cout, hipStream_t s) {
+  if ((C & 7) || (ld & 7)) return -1;
+  const int rpb = 128;
+  dim3 grid((C + 255) / 256, (M + rpb - 1) / rpb);
+  hipLaunchKernelGGL((colsum_kernel<bf16_t, 8>), grid, dim3(256), 0, s, in, ld, out, M, C, Cout, rpb);
+  return 0;
+}
+
+int launch_colsum_f32(const float* in, int ld, float* out, int M, int C, int Cout, hipStream_t s) {
+  if ((C & 3) || (ld & 3)) return -1;
+  const int rpb = 128;
+  dim3 grid((C + 127) / 128, (M + rpb - 1) / rpb);
+  hipLaunchKernelGGL((colsum_kernel<float, 4>), grid, dim3(256), 0, s, in, ld, out, M, C, Cout, rpb);
+  return 0;
+}
+
+int launch_possum(const float* dx, float* dpos, int B, int n, int C, hipStream_t s) {
+  const size_t nC = (size_t)n * C;
+  hipLaunchKernelGGL(possum_kernel, dim3((unsigned)((nC + 255) / 256)), dim3(256), 0, s, dx, dpos, B, nC);
+  return 0;
+}
+
+int launch_mse_loss(const float* pred, const float* target, float* loss_sum, bf16_t* dpred, int B,
+                    int n, int T, int D, int ldp, float gscale, hipStream_t s) {
+  if (T > n || D > ldp) return -1;
+  const float inv_count = 1.0f / ((float)B * (float)T * (float)D);
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(B * n), dim3(256), 0, s, pred, target, loss_sum, dpred, B, n,
+                     T, D, ldp, inv_count, gscale);
+  return 0;
+}
+
+int launch_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, float b1, float b2,
+                float eps, float gscale, hipStream_t s) {
+  if (n & 3) return -1;
+  const size_t n4 = n >> 2;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, 256, 8192)), dim3(256), 0, s, (float4*)p,
+                     (float4*)m, (float4*)v, (float4*)g, n4, lr_t, b1, b2, eps, gscale);
+  return 0;
+}
+
+int launch_cast_transpose(const float* src, int R, int C, bf16_t* dst, int ldd, bf16_t* dstT, int ldt,
+                          hipStream_t s) {
+  dim3 grid((C + 63) / 64, (R + 63) / 64);
+  hipLaunchKernelGGL((cast_transpose_kernel<float>), grid, dim3(256), 0, s, src, C, R, C, dst, ldd,
+                     dstT, ldt);
+  return 0;
+}
+
+int launch_transpose_bf16(const bf16_t* src, int ld, int R, int C, bf16_t* dstT, int ldt,
+                          hipStream_t s) {
+  dim3 grid((C + 63) / 64, (R + 63) / 64);
+  hipLaunchKernelGGL((cast_transpose_kernel<bf16_t>), grid, dim3(256), 0, s, src, ld, R, C,
+                     (bf16_t*)nullptr, 0, dstT, ldt);
+  return 0;
+}
+
+int launch_pad_cast(const float* src, int n, size_t batch_stride, int M, int F, bf16_t* dst, int Fp,
+                    hipStream_t s) {
+  const size_t tot = (size_t)M * Fp;
+  hipLaunchKernelGGL(pad_cast_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, n,
+                     batch_stride, M, F, dst, Fp);
+  return 0;
+}
+
+int launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
+  if (n & 3) return -1;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, s, (const float4*)src,
+                     (bf16x4*)dst, n >> 2);
+  return 0;
+}
+
+int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, bf16_t* da16, float* db,
+                      bf16_t* db16, hipStream_t s) {
+  if (C & 3) return -1;
+  const size_t total = (size_t)B * (na + nb) * (C >> 2);
+  hipLaunchKernelGGL(split_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)dx,
+                     B, na, nb, C >> 2, (float4*)da, (bf16x4*)da16, (float4*)db, (bf16x4*)db16);
+  return 0;
+}
+
+int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s) {
+  if (n & 3) return -1;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, s,
+                     (const float4*)g, n >> 2, out);
+  return 0;
+}

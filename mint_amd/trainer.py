@@ -1,0 +1,172 @@
+"""Train-step host logic: mirror of mint/ctl/single_task_trainer.py (SingleTaskTrainer,
+IdentityMetric) and of the Keras-Adam / Orbit pieces trainer.py wires around it, on top of the
+HIP engine.  Data parallelism is one process per GPU with torch.distributed (backend "nccl" =
+RCCL over xGMI on ROCm, "gloo" in the CPU tests): per-replica loss is divided by the replica count
+and gradients are SUMMED across replicas (single_task_trainer.py:157-158, 186-187).
+"""
+import torch
+
+try:
+    import torch.distributed as dist
+except Exception:  # pragma: no cover
+    dist = None
+
+
+class IdentityMetric:
+    """Metric that reports the last value assigned (single_task_trainer.py:21-47)."""
+
+    def __init__(self, name, aggregation="sum"):
+        self.name = name
+        self.aggregation = aggregation
+        self.value = 0.0
+
+    def update_state(self, current_value):
+        self.value = current_value
+
+    def reset_states(self):
+        self.value = 0.0
+
+    def result(self):
+        v = self.value
+        return float(v.item()) if torch.is_tensor(v) else float(v)
+
+
+class Adam:
+    """tf.keras.optimizers.Adam as trainer.py:150 builds it: Keras defaults beta_1=0.9,
+    beta_2=0.999, epsilon=1e-7 (epsilon outside the bias correction), `learning_rate` a float or a
+    schedule callable evaluated at `iterations`."""
+
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self._lr = learning_rate
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+        self.iterations = 0
+
+    def learning_rate(self, step=None):
+        step = self.iterations if step is None else step
+        return float(self._lr(step)) if callable(self._lr) else float(self._lr)
+
+    def apply_gradients(self, model, clip_norm=0.0):
+        lr = self.learning_rate(self.iterations)
+        model.apply_adam(lr, self.beta_1, self.beta_2, self.epsilon, clip_norm)
+        self.iterations += 1
+        return lr
+
+
+def replica_count():
+    if dist is not None and dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+def allreduce_gradients(grad_arena, bucket_bytes=64 << 20, async_op=False):
+    """Sum the flat fp32 gradient arena across replicas in fixed-size buckets (one RCCL all-reduce
+    per bucket, so the first buckets are on the wire while later ones are still being queued).
+    Returns the list of work handles when async_op is set."""
+    if replica_count() == 1:
+        return []
+    n = grad_arena.numel()
+    step = max(1, bucket_bytes // grad_arena.element_size())
+    works = []
+    for lo in range(0, n, step):
+        w = dist.all_reduce(grad_arena[lo:min(n, lo + step)], op=dist.ReduceOp.SUM, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works
+
+
+class SingleTaskTrainer:
+    """Trains a single-output model on a given dataset (single_task_trainer.py:50-211).
+
+    `train_dataset` is any iterable of feature dicts containing `label_key`; `model` is a
+    mint_amd FACTModel; `loss_fn` is accepted for signature parity (the engine computes the
+    reference's loss, fact_model.py:143-148, fused with the backward pass)."""
+
+    def __init__(self, train_dataset, label_key, model, loss_fn=None, optimizer=None, metrics=None,
+                 trainer_options=None, summary_fn=None, grad_clip_norm=0.0):
+        self.train_dataset = train_dataset
+        self.label_key = label_key
+        self.model = model
+        self.loss_fn = loss_fn
+        self.optimizer = optimizer if optimizer is not None else Adam()
+        self.summary_fn = summary_fn
+        self.grad_clip_norm = grad_clip_norm
+        self.num_replicas_in_sync = replica_count()
+        self.train_loss = IdentityMetric("training_loss", "sum")
+        self.task_loss = IdentityMetric("task_loss", "sum")
+        self.regularization_loss = IdentityMetric("regularization_loss", "sum")
+        self.learning_rate = IdentityMetric("learning_rate", "only_first_replica")
+        if metrics is None:
+            self.metrics = []
+        elif isinstance(metrics, list):
+            self.metrics = metrics
+        else:
+            self.metrics = [metrics]
+        self._iter = None
+
+    def train_loop_begin(self):
+        self.train_loss.reset_states()
+        self.task_loss.reset_states()
+        self.regularization_loss.reset_states()
+        self.learning_rate.reset_states()
+        for metric in self.metrics:
+            metric.reset_states()
+
+    def train_step(self, iterator=None):
+        """One optimizer step (train_fn, single_task_trainer.py:141-196)."""
+        if iterator is None:
+            if self._iter is None:
+                self._iter = iter(self.train_dataset)
+            iterator = self._iter
+        inputs = dict(next(iterator))
+        target = inputs.pop(self.label_key)  # the model never sees it
+        R = self.num_replicas_in_sync
+        raw_loss = self.model.forward_backward(inputs, target, loss_scale=1.0 / R)
+        loss = raw_loss / R
+        regularization_loss = 0.0  # model.losses is empty: no regularisers
+        total_loss = loss + regularization_loss
+        if self.summary_fn:
+            self.summary_fn({"total_loss": total_loss, "loss:": loss, "reg_loss": regularization_loss},
+                            self.optimizer.iterations)
+        allreduce_gradients(self.model.grad_arena)
+        lr = self.optimizer.apply_gradients(self.model, clip_norm=self.grad_clip_norm)
+        self.train_loss.update_state(total_loss)
+        self.task_loss.update_state(loss)
+        self.regularization_loss.update_state(regularization_loss)
+        self.learning_rate.update_state(lr)
+        return total_loss
+
+    def train_loop_end(self):
+        metrics = {m.name: m.result() for m in self.metrics}
+        # the loss metrics aggregate with SUM across replicas (:110-114)
+        vals = []
+        for m in (self.train_loss, self.task_loss, self.regularization_loss):
+            v = m.value
+            vals.append(v.detach().float().reshape(1) if torch.is_tensor(v) else None)
+        if self.num_replicas_in_sync > 1 and all(v is not None for v in vals[:2]):
+            t = torch.cat([vals[0], vals[1]])
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            metrics[self.train_loss.name] = float(t[0].item())
+            metrics[self.task_loss.name] = float(t[1].item())
+        else:
+            metrics[self.train_loss.name] = self.train_loss.result()
+            metrics[self.task_loss.name] = self.task_loss.result()
+        metrics[self.regularization_loss.name] = self.regularization_loss.result()
+        metrics[self.learning_rate.name] = self.learning_rate.result()
+        return metrics
+
+
+def train(trainer, steps, steps_per_loop=10, on_loop_end=None):
+    """Minimal stand-in for orbit.Controller.train (trainer.py:164-178): loops of
+    `steps_per_loop` train steps bracketed by train_loop_begin / train_loop_end."""
+    done, history = 0, []
+    while done < steps:
+        k = min(steps_per_loop, steps - done)
+        trainer.train_loop_begin()
+        for _ in range(k):
+            trainer.train_step()
+        metrics = trainer.train_loop_end()
+        done += k
+        history.append((done, metrics))
+        if on_loop_end:
+            on_loop_end(done, metrics)
+    return history

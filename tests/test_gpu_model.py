@@ -1,0 +1,218 @@
+"""Model-level parity on a real MI355X: the HIP engine (through the FACTModel host mirror and the C
+ABI) against the CPU oracle (oracle/fact_oracle.py, fp64) on the same seeded inputs and the same
+weights.
+
+Stated tolerance (bf16 MFMA operands, fp32 accumulation / residual stream / statistics, vs an
+fp64 oracle of the fp32 reference): forward rel. Frobenius error <= 2e-2, loss (per-frame pose MSE)
+rel. diff <= 1e-2, per-tensor gradient cosine >= 0.99 and rel. Frobenius error <= 8e-2."""
+import pytest
+import torch
+
+from mint_amd import model_builder, protos
+from mint_amd.trainer import Adam, SingleTaskTrainer
+from oracle import fact_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def make_config(cfg):
+    mm = protos.MultiModalModel()
+    fm = mm.fact_model
+    for name in ("audio", "motion"):  # same order as the shipped config (audio first)
+        c = cfg[name]
+        mod = fm.modality.add()
+        mod.feature_name = name
+        mod.sequence_length = c["seq_len"]
+        if name == "motion":
+            mod.feature_dim = c["feature_dim"]  # audio feature_dim left unset like the shipped config
+        t = mod.model.add().transformer
+        t.hidden_size, t.num_hidden_layers = c["hidden"], c["layers"]
+        t.num_attention_heads, t.intermediate_size = c["heads"], c["ff"]
+    cm = fm.cross_modal_model
+    cm.modality_a, cm.modality_b = "motion", "audio"
+    t = cm.transformer
+    t.hidden_size, t.num_hidden_layers = cfg["cross"]["hidden"], cfg["cross"]["layers"]
+    t.num_attention_heads, t.intermediate_size = cfg["cross"]["heads"], cfg["cross"]["ff"]
+    cm.output_layer.out_dim = cfg["out_dim"]
+    return mm
+
+
+def gpu_batch(batch):
+    return {k: v.float().cuda() for k, v in batch.items()}
+
+
+def oracle_params(model, dtype=torch.float64):
+    return {n: v.detach().cpu().to(dtype).clone() for n, v in zip(model.variable_names, model.trainable_variables)}
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def cos(a, b):
+    a, b = a.double().cpu().flatten(), b.double().cpu().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _randomize(model, seed=1):
+    """Non-trivial biases / LN affine so every gradient path is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    for name, v in zip(model.variable_names, model.trainable_variables):
+        if name.endswith("/bias") or name.endswith("/beta"):
+            v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+        elif name.endswith("/gamma"):
+            v.copy_(1.0 + torch.randn(v.shape, generator=g) * 0.1)
+    model.sync_weights()
+
+
+def test_param_table_matches_oracle_order():
+    model = model_builder.build(make_config(O.TINY_CFG), True)
+    model.build(2, 225, 35)
+    names = [n for n, _ in O.param_shapes(O.TINY_CFG)]
+    assert model.variable_names == names
+    for (n, shape), v in zip(O.param_shapes(O.TINY_CFG), model.trainable_variables):
+        assert tuple(v.shape) == tuple(shape), n
+    assert sum(v.numel() for v in model.trainable_variables) == O.num_params(O.TINY_CFG)
+
+
+@pytest.mark.parametrize("wgrad_tr", [1, 0])
+def test_tiny_forward_loss_grads(wgrad_tr):
+    cfg = O.TINY_CFG
+    model = model_builder.build(make_config(cfg), True)
+    batch = O.synthetic_batch(cfg, 4, 8, seed=0)
+    gb = gpu_batch(batch)
+    model.build(4, 225, 35)
+    _randomize(model)
+    model.set_option("wgrad_tr", wgrad_tr)
+    params = oracle_params(model)
+    out = model({"motion_input": gb["motion_input"], "audio_input": gb["audio_input"], "audio_name": "x"})
+    ref = O.fact_forward(params, cfg, batch["motion_input"], batch["audio_input"])
+    assert out.shape == (4, 96, 225)
+    assert rel(out, ref) < 2e-2, rel(out, ref)
+    loss_api = model.loss(gb["target"], out)
+    assert abs(float(loss_api) - float(O.motion_loss(batch["target"], out.double().cpu()))) < 1e-5
+
+    model.grad_arena.zero_()
+    loss = model.forward_backward(gb, gb["target"], loss_scale=0.5)
+    ref_loss, ref_grads, _ = O.loss_and_grads(params, cfg, batch["motion_input"], batch["audio_input"],
+                                              batch["target"], num_replicas=2)
+    assert abs(float(loss) - float(ref_loss)) / float(ref_loss) < 1e-2
+    worst = (1.0, "")
+    for name, g in zip(model.variable_names, model.gradients):
+        r = ref_grads[name]
+        if float(r.norm()) < 1e-12:
+            assert float(g.norm()) < 1e-6, name
+            continue
+        c = cos(g, r)
+        worst = min(worst, (c, name))
+        assert c > 0.99, "%s cos %.5f rel %.4f" % (name, c, rel(g, r))
+        assert rel(g, r) < 8e-2, "%s rel %.4f" % (name, rel(g, r))
+    print("worst gradient cosine", worst)
+
+
+def test_tiny_train_steps_follow_oracle():
+    cfg = O.TINY_CFG
+    model = model_builder.build(make_config(cfg), True)
+    batch = O.synthetic_batch(cfg, 4, 8, seed=3)
+    gb = gpu_batch(batch)
+    model.build(4, 225, 35)
+    params = oracle_params(model)
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(vv) for k, vv in params.items()}
+    trainer = SingleTaskTrainer([gb] * 3, "target", model, optimizer=Adam(1e-3))
+    trainer.train_loop_begin()
+    it = iter([gb] * 3)
+    losses, ref_losses = [], []
+    for step in range(3):
+        losses.append(float(trainer.train_step(it)))
+        l, _, params, m, v = O.train_step(params, m, v, step, cfg, batch, 1e-3)
+        ref_losses.append(float(l))
+    metrics = trainer.train_loop_end()
+    assert metrics["learning_rate"] == pytest.approx(1e-3)
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) / b < 2e-2, (losses, ref_losses)
+    assert ref_losses[2] < ref_losses[0] and losses[2] < losses[0]
+    # parameters after 3 Adam steps: the update direction (p3 - p0) must agree
+    p_now = oracle_params(model)
+    p0 = oracle_params(model_builder_init(cfg))
+    tot_u = torch.cat([(p_now[k] - p0[k]).flatten() for k in params])
+    tot_r = torch.cat([(params[k] - p0[k]).flatten() for k in params])
+    assert cos(tot_u, tot_r) > 0.95, cos(tot_u, tot_r)
+
+
+def model_builder_init(cfg):
+    m = model_builder.build(make_config(cfg), True)
+    m.build(4, 225, 35)
+    return m
+
+
+def test_tiny_autoregressive_matches_oracle():
+    cfg = O.TINY_CFG
+    model = model_builder.build(make_config(cfg), False)
+    g = torch.Generator().manual_seed(5)
+    motion = torch.randn(2, 32, 225, generator=g, dtype=torch.float64)
+    audio = torch.randn(2, 64 + 5, 35, generator=g, dtype=torch.float64)
+    out = model.infer_auto_regressive({"motion_input": motion.float().cuda(), "audio_input": audio.float().cuda()},
+                                      steps=10)
+    assert out.shape == (2, 6, 225)  # audio runs out after 6 windows (fact_model.py:124-126)
+    params = oracle_params(model)
+    ref = O.infer_auto_regressive(params, cfg, motion, audio, steps=10)
+    assert ref.shape == (2, 6, 225)
+    assert rel(out, ref) < 3e-2, rel(out, ref)
+
+
+def test_reference_shape_test_all_ones():
+    """mint/core/fact_model_test.py:23-54: proto defaults (d=768, 12 heads, ff=3072), 2+2+12 layers,
+    all-ones inputs plus ignored mask keys -> (2, 360, 225)."""
+    config = protos.FACTModel()
+    motion = protos.Modality()
+    motion.sequence_length, motion.feature_dim, motion.feature_name = 120, 225, "motion"
+    mm = protos.ModalityModel()
+    mm.transformer.num_hidden_layers = 2
+    motion.model.append(mm)
+    config.modality.append(motion)
+    audio = protos.Modality()
+    audio.sequence_length, audio.feature_name, audio.feature_dim = 240, "audio", 35
+    am = protos.ModalityModel()
+    am.transformer.num_hidden_layers = 2
+    audio.model.append(am)
+    config.modality.append(audio)
+    config.cross_modal_model.modality_a = "motion"
+    config.cross_modal_model.modality_b = "audio"
+    config.cross_modal_model.transformer.num_hidden_layers = 12
+    config.cross_modal_model.output_layer.out_dim = 225
+    from mint_amd import fact_model
+    model = fact_model.FACTModel(config, True)
+    features = {"motion_input": torch.ones(2, 120, 225).cuda(), "motion_mask": torch.ones(2, 120).cuda(),
+                "audio_input": torch.ones(2, 240, 35).cuda(), "audio_mask": torch.ones(2, 240).cuda()}
+    output = model(features)
+    assert tuple(output.shape) == (2, 360, 225)
+    assert torch.isfinite(output).all()
+
+
+def test_fact_v5_forward_and_grads_vs_oracle():
+    """The headline configuration (fact_v5_deeper_t10_cm12) at batch 2, oracle in fp32 on CPU."""
+    cfg = O.FACT_V5_CFG
+    model = model_builder.build(make_config(cfg), True)
+    batch = O.synthetic_batch(cfg, 2, 20, seed=0, dtype=torch.float32)
+    gb = gpu_batch(batch)
+    model.build(2, 225, 35)
+    params = oracle_params(model, torch.float32)
+    assert sum(v.numel() for v in params.values()) == 120406977
+    out = model(gb)
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    ref_loss, ref_grads, ref = O.loss_and_grads(params, cfg, batch["motion_input"], batch["audio_input"],
+                                                batch["target"])
+    assert out.shape == (2, 360, 225)
+    assert rel(out, ref) < 2e-2, rel(out, ref)
+    loss = model.forward_backward(gb, gb["target"])
+    assert abs(float(loss) - float(ref_loss)) / float(ref_loss) < 1e-2
+    names = model.variable_names
+    grads = dict(zip(names, model.gradients))
+    for name in names:
+        if name.endswith("/kernel") or name.endswith("position_embedding"):
+            c = cos(grads[name], ref_grads[name])
+            assert c > 0.98, "%s cos %.4f" % (name, c)
+    # all-reduce friendly invariant: gradients are finite everywhere
+    assert torch.isfinite(model.grad_arena).all()
