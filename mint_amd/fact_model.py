@@ -59,7 +59,10 @@ class FACTModel:
         self.global_step = 0
         self.losses = []  # no regularisers (single_task_trainer.py:163-164 reads this)
         self._seed = seed
-        self._device = torch.device(device if device is not None else "cuda")
+        dev = torch.device(device if device is not None else "cuda")
+        if dev.type == "cuda" and dev.index is None and torch.cuda.is_available():
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self._device = dev
         self._h = None
         self._max_batch = 0
         self._arena = None  # dict of torch tensors: params, grads, adam_m, adam_v

@@ -124,8 +124,8 @@ class _LazyChild:
         parent, name, ftype = self._p
         target = parent._values.get(name, self._m)
         ftype_k = type(target).FIELDS.get(k)
-        if ftype_k and (ftype_k[1] == "repeated" or
-                        (isinstance(ftype_k[0], type) and issubclass(ftype_k[0], Message))):
+        if k in ("CopyFrom", "_set") or (ftype_k and (
+                ftype_k[1] == "repeated" or (isinstance(ftype_k[0], type) and issubclass(ftype_k[0], Message)))):
             target = self._attach()
         return getattr(target, k)
 
