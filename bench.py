@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (headline: 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-phase timing to stderr")
+    ap.add_argument("--side-stream", type=int, default=1, help="0 = single-stream engine (A/B knob)")
     return ap.parse_args()
 
 
@@ -121,6 +122,7 @@ def main():
              "audio_input": torch.randn(B, 240, 35, generator=gen).to(device),
              "target": torch.randn(B, TARGET_LEN, 225, generator=gen).to(device)}
     model.build(B, 225, 35)
+    model.set_option("side_stream", args.side_stream)
     opt = Adam(create_learning_rate(pipe.train_config.learning_rate))
 
     class Repeat:

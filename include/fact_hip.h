@@ -141,6 +141,10 @@ int fact_op_mse(const float* pred, const float* target, float* loss, void* dpred
  * byte_addrs: int[64] per-lane LDS byte address, out: f32[64*4] = what each lane received. */
 int fact_probe_mfma(const float* a_regs, const float* b_regs, float* d_regs, void* stream);
 int fact_probe_tr(const float* lds_vals, int n, const int* byte_addrs, float* out, void* stream);
+/* Test knob: route every GEMM through the register-staged generic kernels (process-global). */
+int fact_debug_force_generic_gemm(int on);
+/* Test/bench knob: NT GEMM kernel choice (0 auto, 1 two-stage 128x128, 2 ring 128x128, 3 ring 256x128). */
+int fact_debug_gemm_nt_variant(int v);
 
 #ifdef __cplusplus
 }

@@ -64,6 +64,8 @@ SIGNATURES = {
     "fact_op_mse": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "fact_probe_mfma": (_i, [_vp, _vp, _vp, _vp]),
     "fact_probe_tr": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "fact_debug_force_generic_gemm": (_i, [_i]),
+    "fact_debug_gemm_nt_variant": (_i, [_i]),
 }
 
 _LIB = None

@@ -6,8 +6,11 @@
 // tile is directly the B operand of the O^T = V^T P^T MFMA (no LDS round trip for P).
 //
 // Per-head operand buffers (written by the QKV GEMM epilogue, EPI_HEADS):
-//   *row : [B*H][NP][DHP]  token-major, head dim zero-padded to a multiple of 32
-//   *tr  : [B*H][DH][NP]   head-dim-major (token-contiguous), NP = round_up(n, 128)
+//   *row : [B*H][NP][DHP]  token-major, head dim zero-padded to a multiple of 32,
+//          NP = round_up(n, 128) with zero rows beyond n.
+// Products that contract over tokens (P V, dS K, dS^T Q, P^T dO) need token-contiguous operand
+// fragments; they are built from the same token-major LDS tiles with the gfx950 LDS transpose
+// read (ds_read_b64_tr_b16), so no transposed copy of q/k/v/dO ever exists in HBM.
 #pragma once
 #include "common.h"
 
@@ -15,11 +18,7 @@ struct AttnParams {
   const bf16_t* qrow;
   const bf16_t* krow;
   const bf16_t* vrow;
-  const bf16_t* qtr;
-  const bf16_t* ktr;
-  const bf16_t* vtr;
   const bf16_t* dorow;
-  const bf16_t* dotr;
   bf16_t* out;        // fwd: attention output [B*n][hid] (b n (h d))
   const bf16_t* o;    // bwd: same tensor, read-only
   float* lse2;        // [B*H][NP] base-2 log-sum-exp of the scaled scores

@@ -11,7 +11,7 @@
 namespace {
 
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr int VS = 36;  // LDS row stride (elements) of a [DH][32-token] transposed tile
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
 
 template <int DH>
 struct Geo {
@@ -41,21 +41,17 @@ DEVINL void stage_rows(bf16_t* dst, const bf16_t* src_tile /* &buf[bh][tok0][0] 
     *reinterpret_cast<bf16x8*>(dst + row * Geo<DH>::KS + ch * 8) = v;
   }
 }
-// stage a [DH][32 tokens] tile of a head-dim-major buffer into LDS (row stride VS)
+// A-operand fragment [16 head-dims of tile dt][32 tokens] built from a token-major LDS tile with the
+// LDS transpose read: lane group g reads the 4x16 block {tokens hh*16 + g*4 .. +3} x {dims dt*16 .. +15};
+// lane s supplies the address of 4 contiguous dims of token hh*16 + g*4 + (s>>2); the hardware hands
+// lane c the 4 token-values of dim dt*16 + c  ->  slots j<4: token g*4+j, j>=4: token 16+g*4+(j-4).
 template <int DH>
-DEVINL void stage_tr(bf16_t* dst, const bf16_t* src_tile /* &buf[bh][0][tok0] */, int NP, int tid) {
-  for (int c = tid; c < DH * 4; c += 256) {
-    const int d = c >> 2, ch = c & 3;
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src_tile + (size_t)d * NP + ch * 8);
-    bf16x4 lo = {v[0], v[1], v[2], v[3]}, hi = {v[4], v[5], v[6], v[7]};
-    *reinterpret_cast<bf16x4*>(dst + d * VS + ch * 8) = lo;
-    *reinterpret_cast<bf16x4*>(dst + d * VS + ch * 8 + 4) = hi;
-  }
-}
-// A-operand fragment of a transposed tile for head-dim tile dt
 DEVINL bf16x8 frag_tr(const bf16_t* t, int dt, int lane) {
-  const bf16_t* p = t + (dt * 16 + (lane & 15)) * VS + (lane >> 4) * 4;
-  return cat4(*reinterpret_cast<const bf16x4*>(p), *reinterpret_cast<const bf16x4*>(p + 16));
+  const int g = lane >> 4, s = lane & 15;
+  const bf16_t* p = t + (g * 4 + (s >> 2)) * Geo<DH>::KS + dt * 16 + (s & 3) * 4;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + 16 * Geo<DH>::KS));
+  return cat4(lo, hi);
 }
 // A-operand fragment of a row tile: 16 tokens (sub), contraction step kd
 template <int DH>
@@ -71,12 +67,11 @@ template <int DH>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   using G = Geo<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * G::KS];
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[DH * VS];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[32 * G::KS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int bh = blockIdx.y;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const size_t row_base = (size_t)bh * p.NP * G::DHP;
-  const size_t tr_base = (size_t)bh * DH * p.NP;
 
   bf16x8 Qf[2][G::KD];
 #pragma unroll
@@ -99,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   const int nkt = (p.n + 31) / 32;
   for (int kt = 0; kt < nkt; ++kt) {
     stage_rows<DH>(Ks, p.krow + row_base + (size_t)kt * 32 * G::DHP, tid);
-    stage_tr<DH>(Vs, p.vtr + tr_base + kt * 32, p.NP, tid);
+    stage_rows<DH>(Vs, p.vrow + row_base + (size_t)kt * 32 * G::DHP, tid);
     __syncthreads();
     f32x4 s[2][2];
 #pragma unroll
@@ -150,7 +145,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     }
 #pragma unroll
     for (int dt = 0; dt < G::ND; ++dt) {
-      const bf16x8 vf = frag_tr(Vs, dt, lane);
+      const bf16x8 vf = frag_tr<DH>(Vs, dt, lane);
 #pragma unroll
       for (int qs = 0; qs < 2; ++qs) O[qs][dt] = mfma16(vf, pb[qs], O[qs][dt]);
     }
@@ -212,12 +207,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   using G = Geo<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * G::KS];
   __shared__ __attribute__((aligned(16))) bf16_t Vr[32 * G::KS];
-  __shared__ __attribute__((aligned(16))) bf16_t Kt[DH * VS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int bh = blockIdx.y;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const size_t row_base = (size_t)bh * p.NP * G::DHP;
-  const size_t tr_base = (size_t)bh * DH * p.NP;
 
   bf16x8 Qf[2][G::KD], dOf[2][G::KD];
   float L2q[2], Dq[2];
@@ -244,7 +237,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   for (int kt = 0; kt < nkt; ++kt) {
     stage_rows<DH>(Ks, p.krow + row_base + (size_t)kt * 32 * G::DHP, tid);
     stage_rows<DH>(Vr, p.vrow + row_base + (size_t)kt * 32 * G::DHP, tid);
-    stage_tr<DH>(Kt, p.ktr + tr_base + kt * 32, p.NP, tid);
     __syncthreads();
     f32x4 s[2][2], dp[2][2];
 #pragma unroll
@@ -283,7 +275,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
     }
 #pragma unroll
     for (int dt = 0; dt < G::ND; ++dt) {
-      const bf16x8 ktf = frag_tr(Kt, dt, lane);
+      const bf16x8 ktf = frag_tr<DH>(Ks, dt, lane);
 #pragma unroll
       for (int qs = 0; qs < 2; ++qs) dQ[qs][dt] = mfma16(ktf, dsb[qs], dQ[qs][dt]);
     }
@@ -315,15 +307,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
   using G = Geo<DH>;
   __shared__ __attribute__((aligned(16))) bf16_t Qs[32 * G::KS];
   __shared__ __attribute__((aligned(16))) bf16_t dOs[32 * G::KS];
-  __shared__ __attribute__((aligned(16))) bf16_t Qt[DH * VS];
-  __shared__ __attribute__((aligned(16))) bf16_t dOt[DH * VS];
   __shared__ __attribute__((aligned(16))) float L2s[32];
   __shared__ __attribute__((aligned(16))) float Dss[32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int bh = blockIdx.y;
   const int key0 = blockIdx.x * 128 + wave * 32;
   const size_t row_base = (size_t)bh * p.NP * G::DHP;
-  const size_t tr_base = (size_t)bh * DH * p.NP;
 
   bf16x8 Kf[2][G::KD], Vf[2][G::KD];
 #pragma unroll
@@ -351,8 +340,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
   for (int qt = 0; qt < nqt; ++qt) {
     stage_rows<DH>(Qs, p.qrow + row_base + (size_t)qt * 32 * G::DHP, tid);
     stage_rows<DH>(dOs, p.dorow + row_base + (size_t)qt * 32 * G::DHP, tid);
-    stage_tr<DH>(Qt, p.qtr + tr_base + qt * 32, p.NP, tid);
-    stage_tr<DH>(dOt, p.dotr + tr_base + qt * 32, p.NP, tid);
     if (tid < 32) L2s[tid] = p.lse2[(size_t)bh * p.NP + qt * 32 + tid];
     else if (tid < 64) Dss[tid - 32] = p.dsum[(size_t)bh * p.NP + qt * 32 + tid - 32];
     __syncthreads();
@@ -396,8 +383,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
     }
 #pragma unroll
     for (int dt = 0; dt < G::ND; ++dt) {
-      const bf16x8 dof = frag_tr(dOt, dt, lane);
-      const bf16x8 qtf = frag_tr(Qt, dt, lane);
+      const bf16x8 dof = frag_tr<DH>(dOs, dt, lane);
+      const bf16x8 qtf = frag_tr<DH>(Qs, dt, lane);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         dV[ks][dt] = mfma16(dof, pb[ks], dV[ks][dt]);

@@ -45,19 +45,24 @@ DEVINL float wave_max(float v) {
 
 // tanh-approximation GELU, the reference's form (mint/core/base_model_util.py:94-107):
 //   0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))
+// tanh(u) = 1 - 2/(1 + e^(2u)) with the hardware exp2 / rcp (v_exp_f32, v_rcp_f32, ~1 ulp):
+// saturates cleanly to +-1 for large |u| (exp2 -> inf -> rcp -> 0, exp2 -> 0 -> 1 - 2).
+DEVINL float fast_tanh(float u) {
+  const float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);  // e^(2u)
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
 DEVINL float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));  // tanh(u), saturates cleanly
+  const float t = fast_tanh(k0 * (x + k1 * x * x * x));
   return 0.5f * x * (1.0f + t);
 }
 
 DEVINL float gelu_tanh_grad(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float x2 = x * x;
-  float u = k0 * (x + k1 * x * x2);
-  float t = 1.0f - 2.0f / (1.0f + __expf(2.0f * u));
-  float du = k0 * (1.0f + 3.0f * k1 * x2);
+  const float x2 = x * x;
+  const float t = fast_tanh(k0 * (x + k1 * x * x2));
+  const float du = k0 * (1.0f + 3.0f * k1 * x2);
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
 

@@ -66,7 +66,6 @@ struct LayerA {
   float *mean1 = nullptr, *rstd1 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
   bf16_t *h1 = nullptr, *a = nullptr, *h2 = nullptr, *pre = nullptr, *g = nullptr;
   bf16_t* row[3] = {nullptr, nullptr, nullptr};
-  bf16_t* tr[3] = {nullptr, nullptr, nullptr};
   float* lse2 = nullptr;
 };
 
@@ -124,15 +123,24 @@ struct FactHandle {
   bf16_t* dh = nullptr;      // [Mc][d]
   bf16_t* dpre = nullptr;    // [Mc][ffmax]
   bf16_t* dqkv = nullptr;    // [Mc][3d]
-  bf16_t *dorow = nullptr, *dotr = nullptr;
+  bf16_t* dorow = nullptr;
   float* dsum = nullptr;
   bf16_t *tA = nullptr, *tB = nullptr;  // transposed operands for the non-tr wgrad path
+  float* ln_ws = nullptr;               // LayerNorm-backward per-block partial column sums
+  CastDesc* cast_table = nullptr;       // device table for the one-launch weight-shadow refresh
+  int cast_n = 0, cast_tiles = 0;
   float* scalars = nullptr;             // [16] device scalars (loss, sumsq)
   bf16_t* ar_x16 = nullptr;             // AR: bf16 hidden rows of token 0 [B][d]
   float* ar_motion = nullptr;           // AR: extended motion track (B, n_m + steps, F_m)
   size_t ar_motion_floats = 0;
   int64_t step = 0;
   int wgrad_tr = 1;
+  // second stream: wgrad GEMMs run beside the dgrad chain, the audio encoder beside the motion encoder
+  int use_side = 1;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> ev;
+  size_t ev_i = 0;
+  hipEvent_t ev_dpre_free = nullptr, ev_dqkv_free = nullptr;  // side-stream readers of dpre / dqkv done
 };
 
 namespace {
@@ -285,7 +293,6 @@ void layout_stack_acts(FactHandle* h, Bump& b, Stack& st, int B) {
     a.g = b.take<bf16_t>(M * st.ff);
     for (int w = 0; w < 3; ++w) {
       a.row[w] = b.take<bf16_t>(BH * st.NP * st.dhp);
-      a.tr[w] = b.take<bf16_t>(BH * st.dh * st.NP);
     }
     a.lse2 = b.take<float>(BH * st.NP);
   }
@@ -318,16 +325,13 @@ void layout_work(FactHandle* h, Bump& b) {
     int ffmax = h->cross.ff;
     if (h->motion.ff > ffmax) ffmax = h->motion.ff;
     if (h->audio.ff > ffmax) ffmax = h->audio.ff;
-    int Hmax = h->cross.H, dhpmax = h->cross.dhp, NPmax = h->cross.NP;
-    size_t rowmax = 0, trmax = 0, lsemax = 0;
+    size_t rowmax = 0, lsemax = 0;
     Stack* sts[3] = {&h->cross, &h->motion, &h->audio};
     for (Stack* st : sts) {
       const size_t BH = (size_t)B * st->H;
       if (BH * st->NP * st->dhp > rowmax) rowmax = BH * st->NP * st->dhp;
-      if (BH * st->dh * st->NP > trmax) trmax = BH * st->dh * st->NP;
       if (BH * st->NP > lsemax) lsemax = BH * st->NP;
     }
-    (void)Hmax; (void)dhpmax; (void)NPmax;
     h->dpred = b.take<bf16_t>(Mc * h->outp);
     h->dx = b.take<float>(Mc * d);
     h->dx16 = b.take<bf16_t>(Mc * d);
@@ -339,8 +343,8 @@ void layout_work(FactHandle* h, Bump& b) {
     h->dpre = b.take<bf16_t>(Mc * ffmax);
     h->dqkv = b.take<bf16_t>(Mc * 3 * d);
     h->dorow = b.take<bf16_t>(rowmax);
-    h->dotr = b.take<bf16_t>(trmax);
     h->dsum = b.take<float>(lsemax);
+    h->ln_ws = b.take<float>(ln_bwd_ws_floats((int)Mc, d));
     const size_t wide = (size_t)(ffmax > 3 * d ? ffmax : 3 * d);
     h->tA = b.take<bf16_t>(wide * rups(Mc, 8));
     h->tB = b.take<bf16_t>(wide * rups(Mc, 8));
@@ -350,29 +354,53 @@ void layout_work(FactHandle* h, Bump& b) {
 float* P(FactHandle* h, const Tensor& t) { return h->params + t.off; }
 float* G(FactHandle* h, const Tensor& t) { return h->grads + t.off; }
 
-int refresh_dense(FactHandle* h, DenseW& w, hipStream_t s) {
-  return launch_cast_transpose(P(h, w.w), w.w.rows, w.w.cols, w.s, w.lds, w.t, w.ldt, s);
-}
-
-int refresh_all(FactHandle* h, hipStream_t s) {
+// Build (once) the device table of every Dense kernel and refresh all bf16 shadows in ONE launch.
+int build_cast_table(FactHandle* h) {
+  std::vector<CastDesc> t;
+  int tiles = 0;
+  auto add = [&](DenseW& w) {
+    CastDesc d;
+    d.src = P(h, w.w);
+    d.s = w.s;
+    d.t = w.t;
+    d.R = w.w.rows;
+    d.C = w.w.cols;
+    d.lds = w.lds;
+    d.ldt = w.ldt;
+    d.tiles_x = (d.C + 63) / 64;
+    d.tile_begin = tiles;
+    tiles += d.tiles_x * ((d.R + 63) / 64);
+    t.push_back(d);
+  };
   Stack* sts[3] = {&h->cross, &h->motion, &h->audio};
   for (Stack* st : sts)
     for (LayerP& p : st->lp) {
-      CHK(refresh_dense(h, p.wqkv, s));
-      CHK(refresh_dense(h, p.wo, s));
-      CHK(refresh_dense(h, p.w1, s));
-      CHK(refresh_dense(h, p.w2, s));
+      add(p.wqkv);
+      add(p.wo);
+      add(p.w1);
+      add(p.w2);
     }
-  CHK(refresh_dense(h, h->head, s));
-  CHK(refresh_dense(h, h->motion.emb, s));
-  CHK(refresh_dense(h, h->audio.emb, s));
+  add(h->head);
+  add(h->motion.emb);
+  add(h->audio.emb);
+  h->cast_n = (int)t.size();
+  h->cast_tiles = tiles;
+  HIPCHK(hipMalloc((void**)&h->cast_table, t.size() * sizeof(CastDesc)));
+  HIPCHK(hipMemcpy(h->cast_table, t.data(), t.size() * sizeof(CastDesc), hipMemcpyHostToDevice));
   return 0;
 }
+
+int refresh_all(FactHandle* h, hipStream_t s) {
+  return launch_multi_cast_transpose(h->cast_table, h->cast_n, h->cast_tiles, s);
+}
+
+int g_force_generic_gemm = 0;  // test knob (fact_debug_force_generic_gemm)
 
 GemmParams gp(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K) {
   GemmParams p;
   memset(&p, 0, sizeof(p));
   p.A = A; p.lda = lda; p.B = B; p.ldb = ldb; p.M = M; p.N = N; p.K = K; p.splitk = 1;
+  p.force_generic = g_force_generic_gemm;
   p.ep.alpha = 1.0f;
   return p;
 }
@@ -382,7 +410,9 @@ int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int 
           float* out, int ldo, hipStream_t s) {
   const int tiles = ((Mo + 127) / 128) * ((No + 127) / 128);
   const int ktiles = (K + 63) / 64;
-  int splitk = (768 + tiles - 1) / tiles;
+  // ~2 blocks per CU: measured optimum on MI355X (tools/gemm_bench.py: 168 tiles -> 3, 49 -> 5..8)
+  int splitk = 560 / tiles;
+  if (splitk > 6) splitk = 6;
   if (splitk > ktiles / 4) splitk = ktiles / 4;
   if (splitk < 1) splitk = 1;
   if (h->wgrad_tr) {
@@ -402,11 +432,8 @@ int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int 
   return launch_gemm_nt(EPI_ATOMIC_F32, p, s);
 }
 
-void heads_ep(EpiParams& ep, const Stack& st, bf16_t* const* row, bf16_t* const* tr, int nwhich) {
-  for (int w = 0; w < 3; ++w) {
-    ep.hrow[w] = (w < nwhich) ? row[w] : nullptr;
-    ep.htr[w] = (w < nwhich) ? tr[w] : nullptr;
-  }
+void heads_ep(EpiParams& ep, const Stack& st, bf16_t* const* row, int nwhich) {
+  for (int w = 0; w < 3; ++w) ep.hrow[w] = (w < nwhich) ? row[w] : nullptr;
   ep.n_tok = st.n;
   ep.n_pad = st.NP;
   ep.heads = st.H;
@@ -419,12 +446,20 @@ AttnParams attn_params(const Stack& st, const LayerA& a, int B) {
   AttnParams ap;
   memset(&ap, 0, sizeof(ap));
   ap.qrow = a.row[0]; ap.krow = a.row[1]; ap.vrow = a.row[2];
-  ap.qtr = a.tr[0]; ap.ktr = a.tr[1]; ap.vtr = a.tr[2];
   ap.out = a.a; ap.o = a.a; ap.lse2 = a.lse2;
   ap.B = B; ap.H = st.H; ap.n = st.n; ap.NP = st.NP; ap.hid = st.d; ap.dh = st.dh;
   ap.scale = 1.0f / sqrtf((float)st.d);  // dim**-0.5 with dim = hidden_size (base_models.py:66,104)
   return ap;
 }
+
+// `to` waits for everything enqueued so far on `from` (no host sync). Returns the event used.
+hipEvent_t stream_after(FactHandle* h, hipStream_t from, hipStream_t to) {
+  hipEvent_t e = h->ev[h->ev_i++ % h->ev.size()];
+  (void)hipEventRecord(e, from);
+  if (to) (void)hipStreamWaitEvent(to, e, 0);
+  return e;
+}
+hipStream_t side_of(FactHandle* h, hipStream_t s) { return (h->use_side && h->side) ? h->side : s; }
 
 int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
   const int M = B * st.n, d = st.d;
@@ -433,7 +468,7 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
   CHK(launch_ln_fwd(a.x_in, P(h, p.ln1_g), P(h, p.ln1_b), a.h1, a.mean1, a.rstd1, M, d, h->cfg.ln_eps, s));
   {
     GemmParams g = gp(a.h1, d, p.wqkv.t, p.wqkv.ldt, M, 3 * d, d);
-    heads_ep(g.ep, st, a.row, a.tr, 3);
+    heads_ep(g.ep, st, a.row, 3);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
   CHK(launch_attn_fwd(attn_params(st, a, B), s));
@@ -461,44 +496,60 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx
   const int M = B * st.n, d = st.d, ff = st.ff;
   LayerP& p = st.lp[l];
   LayerA& a = st.la[l];
+  // The wgrad GEMMs (and the b1 column sum) go to the side stream; the dgrad / attention / LayerNorm
+  // chain stays on `s`.  Events order every producer->consumer and every buffer re-use (dx16 is
+  // rewritten in place by the LayerNorm backward, dpre / dqkv by the next layer).
+  hipStream_t w = side_of(h, s);
+  const bool two = (w != s);
   // ---- MLP block: x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
-  CHK(wgrad(h, a.g, ff, ff, dx16, d, d, M, G(h, p.w2.w), d, s));
+  if (two) stream_after(h, s, w);  // dx16 ready
+  CHK(wgrad(h, a.g, ff, ff, dx16, d, d, M, G(h, p.w2.w), d, w));
+  hipEvent_t e_w2 = two ? stream_after(h, w, nullptr) : nullptr;
+  if (two && h->ev_dpre_free) (void)hipStreamWaitEvent(s, h->ev_dpre_free, 0);
   {
     GemmParams g = gp(dx16, d, p.w2.s, p.w2.lds, M, ff, d);
     g.ep.out0 = h->dpre; g.ep.ldo0 = ff; g.ep.pre = a.pre; g.ep.ldp = ff;
     CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
   }
-  CHK(wgrad(h, a.h2, d, d, h->dpre, ff, ff, M, G(h, p.w1.w), ff, s));
-  CHK(launch_colsum_bf16(h->dpre, ff, G(h, p.b1), M, ff, ff, s));
+  if (two) stream_after(h, s, w);  // dpre ready
+  CHK(wgrad(h, a.h2, d, d, h->dpre, ff, ff, M, G(h, p.w1.w), ff, w));
+  CHK(launch_colsum_bf16(h->dpre, ff, G(h, p.b1), M, ff, ff, w));
+  if (two) h->ev_dpre_free = stream_after(h, w, nullptr);
   {
     GemmParams g = gp(h->dpre, ff, p.w1.s, p.w1.lds, M, d, ff);
     g.ep.out0 = h->dh; g.ep.ldo0 = d;
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
+  if (two) (void)hipStreamWaitEvent(s, e_w2, 0);  // wgrad W2 finished reading dx16
   CHK(launch_ln_bwd(h->dh, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, dx16, G(h, p.ln2_g),
-                    G(h, p.ln2_b), G(h, p.b2), M, d, s));
+                    G(h, p.ln2_b), G(h, p.b2), h->ln_ws, M, d, s));
   // ---- attention block: x_mid = x_in + Wo attn(Wqkv LN1(x_in)) + bo
-  CHK(wgrad(h, a.a, d, d, dx16, d, d, M, G(h, p.wo.w), d, s));
+  if (two) stream_after(h, s, w);  // new dx16 ready
+  CHK(wgrad(h, a.a, d, d, dx16, d, d, M, G(h, p.wo.w), d, w));
+  hipEvent_t e_wo = two ? stream_after(h, w, nullptr) : nullptr;
   {
     GemmParams g = gp(dx16, d, p.wo.s, p.wo.lds, M, d, d);
     bf16_t* row[1] = {h->dorow};
-    bf16_t* tr[1] = {h->dotr};
-    heads_ep(g.ep, st, row, tr, 1);
+    heads_ep(g.ep, st, row, 1);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
+  if (two && h->ev_dqkv_free) (void)hipStreamWaitEvent(s, h->ev_dqkv_free, 0);
   {
     AttnParams ap = attn_params(st, a, B);
-    ap.dorow = h->dorow; ap.dotr = h->dotr; ap.dsum = h->dsum; ap.dqkv = h->dqkv;
+    ap.dorow = h->dorow; ap.dsum = h->dsum; ap.dqkv = h->dqkv;
     CHK(launch_attn_bwd(ap, s));
   }
-  CHK(wgrad(h, a.h1, d, d, h->dqkv, 3 * d, 3 * d, M, G(h, p.wqkv.w), 3 * d, s));
+  if (two) stream_after(h, s, w);  // dqkv ready
+  CHK(wgrad(h, a.h1, d, d, h->dqkv, 3 * d, 3 * d, M, G(h, p.wqkv.w), 3 * d, w));
+  if (two) h->ev_dqkv_free = stream_after(h, w, nullptr);
   {
     GemmParams g = gp(h->dqkv, 3 * d, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
     g.ep.out0 = h->dh; g.ep.ldo0 = d;
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
+  if (two) (void)hipStreamWaitEvent(s, e_wo, 0);  // wgrad Wo finished reading dx16
   CHK(launch_ln_bwd(h->dh, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, dx16, G(h, p.ln1_g),
-                    G(h, p.ln1_b), G(h, p.bo), M, d, s));
+                    G(h, p.ln1_b), G(h, p.bo), h->ln_ws, M, d, s));
   return 0;
 }
 
@@ -514,7 +565,9 @@ int embed_forward(FactHandle* h, Stack& st, const float* in, size_t batch_stride
 
 int embed_backward(FactHandle* h, Stack& st, int B, float* dx, bf16_t* dx16, hipStream_t s) {
   const int M = B * st.n;
-  CHK(wgrad(h, st.xin16, st.featp, st.feat, dx16, st.d, st.d, M, G(h, st.emb.w), st.d, s));
+  hipStream_t w = side_of(h, s);  // all wgrads share the side stream (and its transpose scratch)
+  if (w != s) stream_after(h, s, w);
+  CHK(wgrad(h, st.xin16, st.featp, st.feat, dx16, st.d, st.d, M, G(h, st.emb.w), st.d, w));
   CHK(launch_colsum_f32(dx, st.d, G(h, st.emb_b), M, st.d, st.d, s));
   CHK(launch_possum(dx, G(h, st.pos), B, st.n, st.d, s));
   return 0;
@@ -530,10 +583,13 @@ int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t widt
 int model_forward_hidden(FactHandle* h, const float* motion, size_t m_stride, const float* audio,
                          size_t a_stride, int B, hipStream_t s) {
   Stack &mo = h->motion, &au = h->audio, &cr = h->cross;
+  hipStream_t w = side_of(h, s);
+  if (w != s) stream_after(h, s, w);
+  CHK(embed_forward(h, au, audio, a_stride, B, w));
+  for (int l = 0; l < au.L; ++l) CHK(layer_forward(h, au, l, B, w));
   CHK(embed_forward(h, mo, motion, m_stride, B, s));
   for (int l = 0; l < mo.L; ++l) CHK(layer_forward(h, mo, l, B, s));
-  CHK(embed_forward(h, au, audio, a_stride, B, s));
-  for (int l = 0; l < au.L; ++l) CHK(layer_forward(h, au, l, B, s));
+  if (w != s) stream_after(h, w, s);
   // tf.concat([motion, audio], axis=1)  (base_models.py:192-193)
   const size_t rowb = (size_t)cr.d * sizeof(float);
   CHK(copy2d(cr.x0, (size_t)cr.n * rowb, mo.out(), (size_t)mo.n * rowb, (size_t)mo.n * rowb, B, s));
@@ -635,6 +691,13 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
     b2.base = h->work;
     layout_work(h, b2);
   }
+  {
+    int rc2 = build_cast_table(h);
+    if (rc2) return rc2;
+  }
+  HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  h->ev.resize(64);
+  for (hipEvent_t& e : h->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *out = h;
   return 0;
 }
@@ -649,6 +712,9 @@ int fact_destroy(FactHandle* h) {
   }
   (void)hipFree(h->shadow);
   (void)hipFree(h->work);
+  (void)hipFree(h->cast_table);
+  for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
+  if (h->side) (void)hipStreamDestroy(h->side);
   (void)hipFree(h->ar_motion);
   delete h;
   return 0;
@@ -682,6 +748,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
   if (!h || !key) return fail(-1, "null argument");
   if (!strcmp(key, "wgrad_tr")) {
     h->wgrad_tr = value;
+    return 0;
+  }
+  if (!strcmp(key, "side_stream")) {
+    h->use_side = value;
     return 0;
   }
   return fail(-1, std::string("unknown option ") + key);
@@ -724,7 +794,11 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   CHK(launch_mse_loss(h->pred, target, h->scalars, h->dpred, B, cr.n, T, D, h->outp, loss_scale, s));
   if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, h->scalars, sizeof(float), hipMemcpyDeviceToDevice, s));
   // head backward
-  CHK(wgrad(h, h->xf16, d, d, h->dpred, h->outp, D, Mc, G(h, h->head.w), D, s));
+  {
+    hipStream_t w = side_of(h, s);
+    if (w != s) stream_after(h, s, w);
+    CHK(wgrad(h, h->xf16, d, d, h->dpred, h->outp, D, Mc, G(h, h->head.w), D, w));
+  }
   CHK(launch_colsum_bf16(h->dpred, h->outp, G(h, h->head_b), Mc, h->outp, D, s));
   {
     GemmParams g = gp(h->dpred, h->outp, h->head.s, h->head.lds, Mc, d, h->outp);
@@ -737,6 +811,9 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   CHK(embed_backward(h, au, B, h->dxa, h->dxa16, s));
   for (int l = mo.L - 1; l >= 0; --l) CHK(layer_backward(h, mo, l, B, h->dxm, h->dxm16, s));
   CHK(embed_backward(h, mo, B, h->dxm, h->dxm16, s));
+  if (side_of(h, s) != s) stream_after(h, h->side, s);  // join: the caller's stream sees all gradients
+  h->ev_dpre_free = nullptr;
+  h->ev_dqkv_free = nullptr;
   return 0;
 }
 
@@ -861,20 +938,19 @@ int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const floa
                    const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
                    float* dbeta, float* dbias_prev, int M, int C, void* stream) {
   CHK(launch_ln_bwd((const bf16_t*)dh, x, mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, dgamma, dbeta,
-                    dbias_prev, M, C, (hipStream_t)stream));
+                    dbias_prev, nullptr, M, C, (hipStream_t)stream));
   return 0;
 }
 
 namespace {
 struct AttnScratch {
-  size_t row[4], tr[4], lse, dsum, total;
+  size_t row[4], lse, dsum, total;
 };
 AttnScratch attn_scratch_layout(int B, int H, int n, int dh) {
   AttnScratch a;
   const size_t BH = (size_t)B * H, NP = rup(n, 128), dhp = rup(dh, 32);
   size_t off = 0;
   for (int i = 0; i < 4; ++i) { a.row[i] = off; off += rups(BH * NP * dhp * 2, 256); }
-  for (int i = 0; i < 4; ++i) { a.tr[i] = off; off += rups(BH * dh * NP * 2, 256); }
   a.lse = off; off += rups(BH * NP * 4, 256);
   a.dsum = off; off += rups(BH * NP * 4, 256);
   a.total = off;
@@ -909,35 +985,41 @@ int fact_op_attention(const void* qkv, int B, int H, int n, int dh, float scale,
     HIPCHK(hipStreamSynchronize(s));
   }
   bf16_t* row[4];
-  bf16_t* tr[4];
-  for (int i = 0; i < 4; ++i) { row[i] = (bf16_t*)(sc + L.row[i]); tr[i] = (bf16_t*)(sc + L.tr[i]); }
+  for (int i = 0; i < 4; ++i) row[i] = (bf16_t*)(sc + L.row[i]);
   {
     GemmParams g = gp((const bf16_t*)qkv, W, eye, W, M, W, W);
-    heads_ep(g.ep, st, row, tr, 3);
+    heads_ep(g.ep, st, row, 3);
     int rc = launch_gemm_nt(EPI_HEADS, g, s);
     if (rc) { (void)hipFree(eye); return fail(rc, "heads gemm failed"); }
   }
   AttnParams ap;
   memset(&ap, 0, sizeof(ap));
   ap.qrow = row[0]; ap.krow = row[1]; ap.vrow = row[2];
-  ap.qtr = tr[0]; ap.ktr = tr[1]; ap.vtr = tr[2];
   ap.out = (bf16_t*)out; ap.o = (const bf16_t*)out; ap.lse2 = (float*)(sc + L.lse);
   ap.B = B; ap.H = H; ap.n = n; ap.NP = st.NP; ap.hid = hid; ap.dh = dh; ap.scale = scale;
   int rc = launch_attn_fwd(ap, s);
   if (rc == 0 && dout) {
     GemmParams g = gp((const bf16_t*)dout, hid, eye, W, M, hid, hid);
     bf16_t* r1[1] = {row[3]};
-    bf16_t* t1[1] = {tr[3]};
-    heads_ep(g.ep, st, r1, t1, 1);
+    heads_ep(g.ep, st, r1, 1);
     rc = launch_gemm_nt(EPI_HEADS, g, s);
     if (rc == 0) {
-      ap.dorow = row[3]; ap.dotr = tr[3]; ap.dsum = (float*)(sc + L.dsum); ap.dqkv = (bf16_t*)dqkv;
+      ap.dorow = row[3]; ap.dsum = (float*)(sc + L.dsum); ap.dqkv = (bf16_t*)dqkv;
       rc = launch_attn_bwd(ap, s);
     }
   }
   (void)hipStreamSynchronize(s);
   (void)hipFree(eye);
   if (rc) return fail(rc, "attention launch failed");
+  return 0;
+}
+
+int fact_debug_force_generic_gemm(int on) {
+  g_force_generic_gemm = on;
+  return 0;
+}
+int fact_debug_gemm_nt_variant(int v) {
+  gemm_set_nt_variant(v);
   return 0;
 }
 

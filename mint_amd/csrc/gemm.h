@@ -14,7 +14,7 @@ enum EpiKind : int {
   EPI_F32_BIAS_RESID = 3, // out0 f32  = acc + bias[n] + resid[m][n]
   EPI_BIAS_GELU = 4,      // out0 bf16 = acc + bias[n] (pre-activation), out1 bf16 = gelu(pre)
   EPI_GELU_BWD = 5,       // out0 bf16 = acc * gelu'(pre[m][n])
-  EPI_HEADS = 6,          // scatter to per-head row-major and transposed q/k/v style buffers
+  EPI_HEADS = 6,          // scatter to per-head token-major q/k/v style buffers [B*H][n_pad][dhp]
   EPI_ATOMIC_F32 = 7,     // atomicAdd(out0 f32, alpha * acc)   (split-K wgrad)
   EPI_F32_BF16 = 8,       // out0 f32 = acc, out1 bf16 = acc
 };
@@ -33,7 +33,6 @@ struct EpiParams {
   int ldp;
   // EPI_HEADS: column c -> (which = c / hid, h = (c % hid) / dh, d = c % dh); row -> (b, t)
   bf16_t* hrow[3];  // [B*H][n_pad][dhp]
-  bf16_t* htr[3];   // [B*H][dh][n_pad]
   int n_tok, n_pad, heads, dh, dhp, hid;
   float alpha;
 };
@@ -45,9 +44,11 @@ struct GemmParams {
   int ldb;
   int M, N, K;
   int splitk;
+  int force_generic;  // tests: use the register-staged fallback kernel
   EpiParams ep;
 };
 
 // Launchers. Return 0 on success, negative on invalid arguments.
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);
 int launch_gemm_tn(int epi, const GemmParams& p, hipStream_t stream);
+void gemm_set_nt_variant(int v);  // 0 auto, 1 two-stage, 2 ring 128x128, 3 ring 256x128

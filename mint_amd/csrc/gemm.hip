@@ -1,8 +1,16 @@
 // bf16 MFMA GEMM engine (see gemm.h).  128x128x64 block tile, 256 threads = 4 waves (2x2),
-// each wave a 64x64 sub-tile = 4x4 MFMA 16x16x32 tiles.  Global->register->LDS staging with the
-// next tile's loads in flight during the current tile's MFMAs; double-buffered LDS, one barrier
-// per K step.  LDS images are XOR-swizzled so ds_read_b128 / ds_read_b64_tr_b16 fragment reads
-// are bank-conflict free.
+// each wave a 64x64 sub-tile = 4x4 MFMA 16x16x32 tiles.
+//
+// Fast kernels (gemm_*_fast): operand tiles go HBM -> LDS directly with 16-byte LDS-DMA loads
+//   (global_load_lds_dwordx4: destination = wave-uniform base + lane*16, so the XOR swizzle is
+//   applied to the per-lane SOURCE address and to the fragment reads), double-buffered LDS, the
+//   next tile's DMA in flight under the current tile's MFMAs, one vmcnt(0)+barrier per K step.
+//   Out-of-range rows are clamped (their results are never stored), so no zero-fill is needed.
+// Generic kernels (gemm_*_generic): register-staged with zero-fill, any shape (fallback).
+//
+// MFMA roles are swapped (weights/B tile as the A operand) so that every lane ends up holding
+// 4 CONSECUTIVE OUTPUT COLUMNS of one output row: epilogues load bias/residual and store results
+// with 8/16-byte vector accesses.
 #include "gemm.h"
 
 namespace {
@@ -11,242 +19,489 @@ constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 
 typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
+// One lane's share of the epilogue: output row `row`, columns col0..col0+3 (col0 % 4 == 0).
 template <int EPI>
-DEVINL void epilogue_store(const EpiParams& ep, int M, int N, int row0, int col, f32x4 v) {
-  if (col >= N || row0 >= M) return;
+DEVINL void epilogue_store(const EpiParams& ep, int M, int N, int row, int col0, f32x4 v) {
+  if (row >= M || col0 >= N) return;
+  const bool full = (col0 + 3 < N);
   if constexpr (EPI == EPI_BF16) {
-    bf16_t* o = (bf16_t*)ep.out0;
+    bf16_t* o = (bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col0;
+    if (full && !(ep.ldo0 & 3)) {
+      bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(o) = pk;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (row0 + r < M) o[(size_t)(row0 + r) * ep.ldo0 + col] = (bf16_t)v[r];
-  } else if constexpr (EPI == EPI_F32_BIAS) {
-    float* o = (float*)ep.out0;
-    const float b = ep.bias ? ep.bias[col] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (row0 + r < M) o[(size_t)(row0 + r) * ep.ldo0 + col] = v[r] + b;
-  } else if constexpr (EPI == EPI_F32_BIAS_POS) {
-    float* o = (float*)ep.out0;
-    const float b = ep.bias[col];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + r;
-      if (row < M) o[(size_t)row * ep.ldo0 + col] = v[r] + b + ep.pos[(size_t)(row % ep.seq) * N + col];
+      for (int r = 0; r < 4; ++r)
+        if (col0 + r < N) o[r] = (bf16_t)v[r];
     }
-  } else if constexpr (EPI == EPI_F32_BIAS_RESID) {
-    float* o = (float*)ep.out0;
-    const float b = ep.bias[col];
+  } else if constexpr (EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_POS || EPI == EPI_F32_BIAS_RESID) {
+    float* o = (float*)ep.out0 + (size_t)row * ep.ldo0 + col0;
+    const float* extra = nullptr;
+    if constexpr (EPI == EPI_F32_BIAS_POS) extra = ep.pos + (size_t)(row % ep.seq) * N + col0;
+    if constexpr (EPI == EPI_F32_BIAS_RESID) extra = ep.resid + (size_t)row * ep.ldr + col0;
+    if (full && !(ep.ldo0 & 3) && !(N & 3) && !(ep.ldr & 3)) {
+      float4 b = ep.bias ? *reinterpret_cast<const float4*>(ep.bias + col0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 r = make_float4(v[0] + b.x, v[1] + b.y, v[2] + b.z, v[3] + b.w);
+      if (extra) {
+        const float4 e = *reinterpret_cast<const float4*>(extra);
+        r.x += e.x; r.y += e.y; r.z += e.z; r.w += e.w;
+      }
+      *reinterpret_cast<float4*>(o) = r;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + r;
-      if (row < M) o[(size_t)row * ep.ldo0 + col] = v[r] + b + ep.resid[(size_t)row * ep.ldr + col];
+      for (int r = 0; r < 4; ++r)
+        if (col0 + r < N) o[r] = v[r] + (ep.bias ? ep.bias[col0 + r] : 0.f) + (extra ? extra[r] : 0.f);
     }
   } else if constexpr (EPI == EPI_BIAS_GELU) {
-    bf16_t* o0 = (bf16_t*)ep.out0;
-    bf16_t* o1 = (bf16_t*)ep.out1;
-    const float b = ep.bias[col];
+    bf16_t* o0 = (bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col0;
+    bf16_t* o1 = (bf16_t*)ep.out1 + (size_t)row * ep.ldo1 + col0;
+    float pre[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + r;
-      if (row < M) {
-        const float pre = v[r] + b;
-        o0[(size_t)row * ep.ldo0 + col] = (bf16_t)pre;
-        o1[(size_t)row * ep.ldo1 + col] = (bf16_t)gelu_tanh(pre);
-      }
+    for (int r = 0; r < 4; ++r) pre[r] = v[r] + ((col0 + r < N) ? ep.bias[col0 + r] : 0.f);
+    if (full && !(ep.ldo0 & 3) && !(ep.ldo1 & 3)) {
+      bf16x4 p0 = {(bf16_t)pre[0], (bf16_t)pre[1], (bf16_t)pre[2], (bf16_t)pre[3]};
+      bf16x4 p1 = {(bf16_t)gelu_tanh(pre[0]), (bf16_t)gelu_tanh(pre[1]), (bf16_t)gelu_tanh(pre[2]),
+                   (bf16_t)gelu_tanh(pre[3])};
+      *reinterpret_cast<bf16x4*>(o0) = p0;
+      *reinterpret_cast<bf16x4*>(o1) = p1;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col0 + r < N) {
+          o0[r] = (bf16_t)pre[r];
+          o1[r] = (bf16_t)gelu_tanh(pre[r]);
+        }
     }
   } else if constexpr (EPI == EPI_GELU_BWD) {
-    bf16_t* o = (bf16_t*)ep.out0;
+    bf16_t* o = (bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col0;
+    const bf16_t* pp = ep.pre + (size_t)row * ep.ldp + col0;
+    if (full && !(ep.ldo0 & 3) && !(ep.ldp & 3)) {
+      const bf16x4 pv = *reinterpret_cast<const bf16x4*>(pp);
+      bf16x4 pk = {(bf16_t)(v[0] * gelu_tanh_grad((float)pv[0])), (bf16_t)(v[1] * gelu_tanh_grad((float)pv[1])),
+                   (bf16_t)(v[2] * gelu_tanh_grad((float)pv[2])), (bf16_t)(v[3] * gelu_tanh_grad((float)pv[3]))};
+      *reinterpret_cast<bf16x4*>(o) = pk;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = row0 + r;
-      if (row < M) {
-        const float pre = (float)ep.pre[(size_t)row * ep.ldp + col];
-        o[(size_t)row * ep.ldo0 + col] = (bf16_t)(v[r] * gelu_tanh_grad(pre));
-      }
+      for (int r = 0; r < 4; ++r)
+        if (col0 + r < N) o[r] = (bf16_t)(v[r] * gelu_tanh_grad((float)pp[r]));
     }
   } else if constexpr (EPI == EPI_HEADS) {
-    const int which = col / ep.hid;
-    const int rem = col - which * ep.hid;
+    // column c -> (which, h, d); dh % 4 == 0 so the 4 columns share (which, h)
+    const int which = col0 / ep.hid;
+    const int rem = col0 - which * ep.hid;
     const int h = rem / ep.dh;
     const int d = rem - h * ep.dh;
+    const int b = row / ep.n_tok;
+    const int t = row - b * ep.n_tok;
     bf16_t* hr = ep.hrow[which];
-    bf16_t* ht = ep.htr[which];
-    const int b0 = row0 / ep.n_tok;
-    const int t0 = row0 - b0 * ep.n_tok;
-    const bool vec = ((ep.n_tok & 3) == 0) && (row0 + 3 < M);
     if (hr) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = row0 + r;
-        if (row < M) {
-          int b = b0, t = t0 + r;
-          if (!vec) { b = row / ep.n_tok; t = row - b * ep.n_tok; }
-          hr[((size_t)(b * ep.heads + h) * ep.n_pad + t) * ep.dhp + d] = (bf16_t)v[r];
-        }
-      }
-    }
-    if (ht) {
-      if (vec) {
-        bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-        *reinterpret_cast<bf16x4*>(ht + ((size_t)(b0 * ep.heads + h) * ep.dh + d) * ep.n_pad + t0) = pk;
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = row0 + r;
-          if (row < M) {
-            const int b = row / ep.n_tok, t = row - b * ep.n_tok;
-            ht[((size_t)(b * ep.heads + h) * ep.dh + d) * ep.n_pad + t] = (bf16_t)v[r];
-          }
-        }
-      }
+      bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(hr + ((size_t)(b * ep.heads + h) * ep.n_pad + t) * ep.dhp + d) = pk;
     }
   } else if constexpr (EPI == EPI_F32_BF16) {
-    float* o0 = (float*)ep.out0;
-    bf16_t* o1 = (bf16_t*)ep.out1;
+    float* o0 = (float*)ep.out0 + (size_t)row * ep.ldo0 + col0;
+    bf16_t* o1 = (bf16_t*)ep.out1 + (size_t)row * ep.ldo1 + col0;
+    if (full && !(ep.ldo0 & 3) && !(ep.ldo1 & 3)) {
+      *reinterpret_cast<float4*>(o0) = make_float4(v[0], v[1], v[2], v[3]);
+      bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(o1) = pk;
+    } else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (row0 + r < M) {
-        o0[(size_t)(row0 + r) * ep.ldo0 + col] = v[r];
-        o1[(size_t)(row0 + r) * ep.ldo1 + col] = (bf16_t)v[r];
-      }
+      for (int r = 0; r < 4; ++r)
+        if (col0 + r < N) {
+          o0[r] = v[r];
+          o1[r] = (bf16_t)v[r];
+        }
+    }
   } else if constexpr (EPI == EPI_ATOMIC_F32) {
-    float* o = (float*)ep.out0;
+    float* o = (float*)ep.out0 + (size_t)row * ep.ldo0 + col0;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (row0 + r < M) atomicAdd(o + (size_t)(row0 + r) * ep.ldo0 + col, v[r] * ep.alpha);
+      if (col0 + r < N) atomicAdd(o + r, v[r] * ep.alpha);
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// NT: A[m*lda + k], B[n*ldb + k]
-// LDS image of a [128 rows][64 k] tile: 128-byte rows, 16-byte chunk c of row r stored at
-// r*128 + ((c ^ (r & 7)) << 4): the 16 lanes of a ds_read_b128 service group land on 16 distinct
-// 16-byte bank slots.
-// ------------------------------------------------------------------------------------------
+// The atomic (split-K wgrad) epilogue keeps the un-swapped MFMA roles: a lane then holds 4 consecutive
+// ROWS of one column and the 16 lanes of a group hit 16 consecutive floats -> coalesced atomics.
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+constexpr bool kSwap = (EPI != EPI_ATOMIC_F32);
 
+// swapped:    acc[i][j] = rows m0+wm*64+i*16+(lane&15),       cols n0+wn*64+j*16+(lane>>4)*4 + r
+// un-swapped: acc[i][j] = rows m0+wm*64+i*16+(lane>>4)*4 + r,  cols n0+wn*64+j*16+(lane&15)
+template <int EPI>
+DEVINL void run_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if constexpr (kSwap<EPI>) {
+        const int row = m0 + wm * 64 + i * 16 + (lane & 15);
+        const int col0 = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        epilogue_store<EPI>(p.ep, p.M, p.N, row, col0, acc[i][j]);
+      } else {
+        const int row0 = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
+        const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+        if (col < p.N) {
+          float* o = (float*)p.ep.out0 + (size_t)row0 * p.ep.ldo0 + col;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (row0 + r < p.M) atomicAdd(o + (size_t)r * p.ep.ldo0, acc[i][j][r] * p.ep.alpha);
+        }
+      }
+    }
+  }
+}
+
+// Block -> (m-tile, n-tile, k-split).  The 1-D grid is re-dealt so that each of the 8 XCDs (block b
+// runs on XCD b % 8, observed) owns a CONTIGUOUS range of logical tile ids: neighbouring tiles share
+// A-row / B-column panels, so the re-reads hit that XCD's private 4 MiB L2 instead of the fabric.
+// Bijective for any grid size (cdna guide T1).  Logical id order: k-split fastest, then n, then m.
+struct BlockCoord {
+  int m0, n0, z;
+};
+DEVINL BlockCoord block_coord(const GemmParams& p) {
+  const int tn = (p.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  BlockCoord c;
+  c.z = id % p.splitk;
+  const int t = id / p.splitk;
+  c.n0 = (t % tn) * BN;
+  c.m0 = (t / tn) * BM;
+  return c;
+}
+
+DEVINL void split_range(const GemmParams& p, int z, int& kt_beg, int& kt_end) {
   const int ktiles = (p.K + BK - 1) / BK;
   const int per = (ktiles + p.splitk - 1) / p.splitk;
-  const int kt_beg = blockIdx.z * per;
-  const int kt_end = min(ktiles, kt_beg + per);
-  if (kt_beg >= kt_end) return;
+  kt_beg = z * per;
+  kt_end = min(ktiles, kt_beg + per);
+}
 
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+// ---- LDS images ---------------------------------------------------------------------------------
+// NT tile [128 rows][64 k]: 128-byte rows; logical 16-byte chunk c of row r sits at chunk position
+//   c ^ (r & 7): the 16 lanes of a ds_read_b128 service group hit 16 distinct 16-byte bank slots.
+// TN tile [64 k][128 m]: 256-byte rows; logical 32-byte unit u of row k sits at unit position
+//   u ^ f(k), f(k) = (k&3) | ((k>>3)&1)<<2: the 8 row-segments one ds_read_b64_tr_b16 service group
+//   touches fall in 8 distinct 32-byte bank slots.
+DEVINL int tn_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
 
-  bf16x8 ra[4], rb[4];
-  const bf16x8 zero = zero_bf16x8();
+DEVINL bf16x8 nt_frag(const unsigned char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((chunk ^ (row & 7)) << 4));
+}
 
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK;
+// TN fragment via the LDS transpose read: for k-slot group g = lane>>4, lane s = lane&15 supplies
+// the address of 4 contiguous m-elements of row k = g*8 + hh*4 + (s>>2), columns (s&3)*4..+3; the
+// hardware hands lane c the 4 k-values of column c (verified by tests/test_gpu_ops.py probe).
+DEVINL bf16x8 tn_frag(const unsigned char* tile, int ks, int u, int lane) {
+  const int g = lane >> 4, s = lane & 15;
+  bf16x4 r[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 256;
-      const int row = c >> 3, kc = c & 7;
-      const int k = k0 + kc * 8;
-      const int gm = m0 + row, gn = n0 + row;
-      ra[i] = (gm < p.M && k < p.K) ? ld_global_bf16x8(p.A + (size_t)gm * p.lda + k) : zero;
-      rb[i] = (gn < p.N && k < p.K) ? ld_global_bf16x8(p.B + (size_t)gn * p.ldb + k) : zero;
-    }
-  };
-  auto sstore = [&](int buf) {
-    unsigned char* As = smem + buf * 2 * TILE_BYTES;
-    unsigned char* Bs = As + TILE_BYTES;
+  for (int hh = 0; hh < 2; ++hh) {
+    const int k = ks * 32 + g * 8 + hh * 4 + (s >> 2);
+    const int off = k * 256 + ((u ^ tn_f(k)) << 5) + (s & 3) * 8;
+    r[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off));
+  }
+  bf16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+  return f;
+}
+
+template <bool TN, bool SWAP>
+DEVINL void compute_tile(const unsigned char* As, const unsigned char* Bs, f32x4 (&acc)[4][4], int nks,
+                         int wm, int wn, int lane) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 256;
-      const int row = c >> 3, kc = c & 7;
-      const int off = row * 128 + ((kc ^ (row & 7)) << 4);
-      *reinterpret_cast<bf16x8*>(As + off) = ra[i];
-      *reinterpret_cast<bf16x8*>(Bs + off) = rb[i];
-    }
-  };
-  auto compute = [&](int buf) {
-    const unsigned char* As = smem + buf * 2 * TILE_BYTES;
-    const unsigned char* Bs = As + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < 2; ++ks) {
+    if (ks < nks) {
       bf16x8 af[4], bfr[4];
-      const int chunk = ks * 4 + (lane >> 4);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = wm * 64 + i * 16 + (lane & 15);
-        af[i] = *reinterpret_cast<const bf16x8*>(As + row * 128 + ((chunk ^ (row & 7)) << 4));
+        if constexpr (TN) af[i] = tn_frag(As, ks, wm * 4 + i, lane);
+        else af[i] = nt_frag(As, wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int row = wn * 64 + j * 16 + (lane & 15);
-        bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + row * 128 + ((chunk ^ (row & 7)) << 4));
+        if constexpr (TN) bfr[j] = tn_frag(Bs, ks, wn * 4 + j, lane);
+        else bfr[j] = nt_frag(Bs, wn * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
       }
+      // swapped roles: D[row = n-local][col = m-local]; un-swapped: D[row = m-local][col = n-local]
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
     }
-  };
-
-  gload(kt_beg);
-  sstore(0);
-  __syncthreads();
-  int buf = 0;
-  for (int kt = kt_beg; kt < kt_end; ++kt) {
-    const bool more = (kt + 1 < kt_end);
-    if (more) gload(kt + 1);
-    compute(buf);
-    if (more) sstore(buf ^ 1);
-    __syncthreads();
-    buf ^= 1;
   }
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row0 = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
-      const int col = n0 + wn * 64 + j * 16 + (lane & 15);
-      epilogue_store<EPI>(p.ep, p.M, p.N, row0, col, acc[i][j]);
-    }
 }
 
-// ------------------------------------------------------------------------------------------
-// TN: A[k*lda + m], B[k*ldb + n]  (wgrad: contraction over the token rows of both operands)
-// LDS image of a [64 k][128 m] tile: 256-byte rows; 32-byte unit u (16 elements) of row k is
-// stored at unit u ^ f(k), f(k) = (k&3) | ((k>>3)&1)<<2, so the 8 row-segments touched by one
-// 32-lane ds_read_b64_tr_b16 service group fall in 8 distinct 32-byte bank slots.
-// Fragment build: for MFMA k-slot group g = lane>>4, lane s = lane&15 supplies the address of
-// 4 contiguous m-elements of row k = g*8 + hh*4 + (s>>2), columns (s&3)*4..+3; the hardware
-// returns to lane c the 4 k-values of column c (ck_tile LaneGroupTransposeTraits: 4x16 -> 16x4).
-// ------------------------------------------------------------------------------------------
-DEVINL int tn_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-
-  const int ktiles = (p.K + BK - 1) / BK;
-  const int per = (ktiles + p.splitk - 1) / p.splitk;
-  const int kt_beg = blockIdx.z * per;
-  const int kt_end = min(ktiles, kt_beg + per);
-  if (kt_beg >= kt_end) return;
-
-  f32x4 acc[4][4];
+DEVINL void zero_acc(f32x4 (&acc)[4][4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
 
+DEVINL void glds16(const bf16_t* src, unsigned char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// fast NT: A[m*lda + k], B[n*ldb + k]; requires K % 32 == 0
+// ------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nt_fast_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const BlockCoord bc = block_coord(p);
+  const int m0 = bc.m0, n0 = bc.n0;
+  int kt_beg, kt_end;
+  split_range(p, bc.z, kt_beg, kt_end);
+  if (kt_beg >= kt_end) return;
+
+  f32x4 acc[4][4];
+  zero_acc(acc);
+
+  // DMA piece i of this wave covers tile rows (wave*4+i)*8 .. +7; lane -> row lane>>3, LDS chunk
+  // position lane&7, which must receive logical chunk (lane&7) ^ (row&7).
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ lrow;
+  const bf16_t* arow[4];
+  const bf16_t* brow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = (wave * 4 + i) * 8 + lrow;
+    arow[i] = p.A + (size_t)min(m0 + r, p.M - 1) * p.lda;
+    brow[i] = p.B + (size_t)min(n0 + r, p.N - 1) * p.ldb;
+  }
+  auto stage = [&](int buf, int kt) {
+    int k = kt * BK + lchunk * 8;
+    if (k >= p.K) k -= 32;  // K-tail (K % 64 == 32): duplicate valid data, ks = 1 is skipped
+    unsigned char* As = smem + buf * 2 * TILE_BYTES + wave * 4096;
+    unsigned char* Bs = As + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(arow[i] + k, As + i * 1024);
+      glds16(brow[i] + k, Bs + i * 1024);
+    }
+  };
+
+  stage(0, kt_beg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    if (kt + 1 < kt_end) stage(buf ^ 1, kt + 1);
+    const unsigned char* As = smem + buf * 2 * TILE_BYTES;
+    const int nks = (p.K - kt * BK >= BK) ? 2 : 1;
+    compute_tile<false, kSwap<EPI>>(As, As + TILE_BYTES, acc, nks, wm, wn, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf ^= 1;
+  }
+  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// ring NT: (WM*64) x 128 block tile, 2*WM waves, BK = 32 stages in an NSTAGE-deep LDS ring.
+// The LDS-DMA latency under load (~1-1.5 us) is several K steps long, so NSTAGE-1 stages stay in
+// flight: each step waits with a COUNTED vmcnt for the oldest stage only, crosses one raw
+// s_barrier, re-arms the slot freed by the previous step and runs 16 MFMAs per wave.
+// Stage image: [rows][32 k] = 64-byte rows; logical 16-byte chunk c of row r sits at position
+// c ^ G[(r>>2)&3], G = {0,2,3,1}: every ds_read_b128 service group (rows {0-3,12-15} of one k-chunk
+// plus rows {4-11} of the next) lands on 16 distinct 16-byte bank slots.
+// ------------------------------------------------------------------------------------------
+DEVINL int ring_g(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+template <int BKR>
+DEVINL int ring_swz(int row) {
+  if constexpr (BKR == 64) return row & 7;
+  else return ring_g(row);
+}
+template <int BKR>
+DEVINL bf16x8 ring_frag(const unsigned char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * (BKR * 2) + ((chunk ^ ring_swz<BKR>(row)) << 4));
+}
+
+template <int N>
+DEVINL void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `stages_after` later stages (LPS loads each) are still in flight
+template <int LPS>
+DEVINL void wait_stages(int stages_after) {
+  switch (stages_after) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<LPS>(); break;
+    case 2: wait_vmcnt<2 * LPS>(); break;
+    case 3: wait_vmcnt<3 * LPS>(); break;
+    default: wait_vmcnt<4 * LPS>(); break;
+  }
+}
+
+// BKR = 64: 128-byte rows (full cache lines per DMA row, chunk position c ^ (r&7));
+// BKR = 32: 64-byte rows (G swizzle above).
+template <int EPI, int WM, int NSTAGE, int BKR>
+__global__ __launch_bounds__(WM * 128, 2) void gemm_nt_ring_kernel(const GemmParams p) {
+  constexpr int RBM = WM * 64;                 // block rows
+  constexpr int NW = WM * 2;                   // waves
+  constexpr int ROWB = BKR * 2;                // bytes per tile row
+  constexpr int RPP = 1024 / ROWB;             // rows per 1-KiB DMA piece
+  constexpr int CPR = ROWB / 16;               // 16-byte chunks per row
+  constexpr int A_BYTES = RBM * ROWB;          // one stage of A
+  constexpr int STAGE_BYTES = A_BYTES + 128 * ROWB;
+  constexpr int APW = RBM / RPP / NW;          // A pieces per wave
+  constexpr int BPW = 128 / RPP / NW;          // B pieces per wave
+  constexpr int LPS = APW + BPW;               // LDS-DMA loads per thread per stage
+  constexpr int DIST = NSTAGE - 1;             // prefetch distance (<= 5)
+  constexpr int KSUB = BKR / 32;
+  static_assert(DIST >= 1 && DIST <= 5 && APW >= 1 && BPW >= 1 && 4 * LPS < 64, "ring geometry");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // block -> tile (same XCD-contiguous re-deal as block_coord, with this kernel's tile height)
+  const int tn = (p.N + BN - 1) / BN;
+  int m0, n0;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    n0 = (id % tn) * BN;
+    m0 = (id / tn) * RBM;
+  }
+  const int nk = (p.K + BKR - 1) / BKR;
+
+  f32x4 acc[4][4];
+  zero_acc(acc);
+
+  // DMA piece = RPP rows; lane -> row lane/CPR, LDS chunk position lane%CPR <- logical chunk
+  const int lrow = lane / CPR;
+  const int lchunk = (lane % CPR) ^ ring_swz<BKR>(lrow);
+  const bf16_t* asrc[APW];
+  const bf16_t* bsrc[BPW];
+#pragma unroll
+  for (int i = 0; i < APW; ++i)
+    asrc[i] = p.A + (size_t)min(m0 + (wave * APW + i) * RPP + lrow, p.M - 1) * p.lda;
+#pragma unroll
+  for (int i = 0; i < BPW; ++i)
+    bsrc[i] = p.B + (size_t)min(n0 + (wave * BPW + i) * RPP + lrow, p.N - 1) * p.ldb;
+
+  auto stage = [&](int kt) {
+    unsigned char* base = smem + (kt % NSTAGE) * STAGE_BYTES;
+    int k = kt * BKR + lchunk * 8;
+    if (k >= p.K) k -= 32;  // K tail of a 64-deep stage (K % 64 == 32): duplicate, ks = 1 is skipped
+#pragma unroll
+    for (int i = 0; i < APW; ++i) glds16(asrc[i] + k, base + (wave * APW + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < BPW; ++i) glds16(bsrc[i] + k, base + A_BYTES + (wave * BPW + i) * 1024);
+  };
+
+#pragma unroll
+  for (int s = 0; s < DIST; ++s)
+    if (s < nk) stage(s);
+
+  for (int kt = 0; kt < nk; ++kt) {
+    wait_stages<LPS>(min(DIST - 1, nk - 1 - kt));
+    __builtin_amdgcn_s_barrier();
+    if (kt + DIST < nk) stage(kt + DIST);
+    const unsigned char* As = smem + (kt % NSTAGE) * STAGE_BYTES;
+    const unsigned char* Bs = As + A_BYTES;
+    const int nks = (KSUB == 2 && p.K - kt * BKR < BKR) ? 1 : KSUB;
+#pragma unroll
+    for (int ks = 0; ks < KSUB; ++ks) {
+      if (ks < nks) {
+        bf16x8 af[4], bfr[4];
+        const int chunk = ks * 4 + (lane >> 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = ring_frag<BKR>(As, wm * 64 + i * 16 + (lane & 15), chunk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = ring_frag<BKR>(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = kSwap<EPI> ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+      }
+    }
+  }
+  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// fast TN: A[k*lda + m], B[k*ldb + n]; requires K % 64 == 0
+// ------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tn_fast_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const BlockCoord bc = block_coord(p);
+  const int m0 = bc.m0, n0 = bc.n0;
+  int kt_beg, kt_end;
+  split_range(p, bc.z, kt_beg, kt_end);
+  if (kt_beg >= kt_end) return;
+
+  f32x4 acc[4][4];
+  zero_acc(acc);
+
+  // DMA piece i of this wave covers tile rows k = (wave*4+i)*4 .. +3; lane -> row lane>>4, LDS
+  // chunk position p = lane&15 which must receive logical chunk ((p>>1) ^ f(k))<<1 | (p&1).
+  const int lk = lane >> 4, lp = lane & 15;
+  int acol[4], bcol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = (wave * 4 + i) * 4 + lk;
+    const int mc = ((((lp >> 1) ^ tn_f(k)) << 1) | (lp & 1)) * 8;
+    acol[i] = min(m0 + mc, p.lda - 8);
+    bcol[i] = min(n0 + mc, p.ldb - 8);
+  }
+  auto stage = [&](int buf, int kt) {
+    unsigned char* As = smem + buf * 2 * TILE_BYTES + wave * 4096;
+    unsigned char* Bs = As + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const size_t k = (size_t)kt * BK + (wave * 4 + i) * 4 + lk;
+      glds16(p.A + k * p.lda + acol[i], As + i * 1024);
+      glds16(p.B + k * p.ldb + bcol[i], Bs + i * 1024);
+    }
+  };
+
+  stage(0, kt_beg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    if (kt + 1 < kt_end) stage(buf ^ 1, kt + 1);
+    const unsigned char* As = smem + buf * 2 * TILE_BYTES;
+    compute_tile<true, kSwap<EPI>>(As, As + TILE_BYTES, acc, 2, wm, wn, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf ^= 1;
+  }
+  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// generic kernels: register-staged, zero-filled bounds (any M, N; K % 8 == 0 for NT)
+// ------------------------------------------------------------------------------------------
+template <int EPI, bool TN>
+__global__ __launch_bounds__(256, 2) void gemm_generic_kernel(const GemmParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const BlockCoord bc = block_coord(p);
+  const int m0 = bc.m0, n0 = bc.n0;
+  int kt_beg, kt_end;
+  split_range(p, bc.z, kt_beg, kt_end);
+  if (kt_beg >= kt_end) return;
+
+  f32x4 acc[4][4];
+  zero_acc(acc);
   bf16x8 ra[4], rb[4];
   const bf16x8 zero = zero_bf16x8();
 
@@ -255,11 +510,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + i * 256;
-      const int krow = c >> 4, mc = c & 15;
-      const int k = k0 + krow;
-      const int gm = m0 + mc * 8, gn = n0 + mc * 8;
-      ra[i] = (k < p.K && gm < p.lda) ? ld_global_bf16x8(p.A + (size_t)k * p.lda + gm) : zero;
-      rb[i] = (k < p.K && gn < p.ldb) ? ld_global_bf16x8(p.B + (size_t)k * p.ldb + gn) : zero;
+      if constexpr (!TN) {
+        const int row = c >> 3, kc = c & 7;
+        const int k = k0 + kc * 8;
+        const int gm = m0 + row, gn = n0 + row;
+        ra[i] = (gm < p.M && k < p.K) ? ld_global_bf16x8(p.A + (size_t)gm * p.lda + k) : zero;
+        rb[i] = (gn < p.N && k < p.K) ? ld_global_bf16x8(p.B + (size_t)gn * p.ldb + k) : zero;
+      } else {
+        const int krow = c >> 4, mc = c & 15;
+        const int k = k0 + krow;
+        const int gm = m0 + mc * 8, gn = n0 + mc * 8;
+        ra[i] = (k < p.K && gm < p.lda) ? ld_global_bf16x8(p.A + (size_t)k * p.lda + gm) : zero;
+        rb[i] = (k < p.K && gn < p.ldb) ? ld_global_bf16x8(p.B + (size_t)k * p.ldb + gn) : zero;
+      }
     }
   };
   auto sstore = [&](int buf) {
@@ -268,38 +531,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + i * 256;
-      const int krow = c >> 4, mc = c & 15;
-      const int off = krow * 256 + (((((mc >> 1) ^ tn_f(krow)) << 1) | (mc & 1)) << 4);
+      int off;
+      if constexpr (!TN) {
+        const int row = c >> 3, kc = c & 7;
+        off = row * 128 + ((kc ^ (row & 7)) << 4);
+      } else {
+        const int krow = c >> 4, mc = c & 15;
+        off = krow * 256 + (((((mc >> 1) ^ tn_f(krow)) << 1) | (mc & 1)) << 4);
+      }
       *reinterpret_cast<bf16x8*>(As + off) = ra[i];
       *reinterpret_cast<bf16x8*>(Bs + off) = rb[i];
-    }
-  };
-  auto tr_frag = [&](const unsigned char* tile, int ks, int u) -> bf16x8 {
-    const int g = lane >> 4, s = lane & 15;
-    bf16x4 r[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const int k = ks * 32 + g * 8 + hh * 4 + (s >> 2);
-      const int off = k * 256 + ((u ^ tn_f(k)) << 5) + (s & 3) * 8;
-      r[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off));
-    }
-    bf16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
-    return f;
-  };
-  auto compute = [&](int buf) {
-    const unsigned char* As = smem + buf * 2 * TILE_BYTES;
-    const unsigned char* Bs = As + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = tr_frag(As, ks, wm * 4 + i);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[j] = tr_frag(Bs, ks, wn * 4 + j);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
     }
   };
 
@@ -310,32 +551,45 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const GemmParams p) {
   for (int kt = kt_beg; kt < kt_end; ++kt) {
     const bool more = (kt + 1 < kt_end);
     if (more) gload(kt + 1);
-    compute(buf);
+    const unsigned char* As = smem + buf * 2 * TILE_BYTES;
+    compute_tile<TN, kSwap<EPI>>(As, As + TILE_BYTES, acc, 2, wm, wn, lane);
     if (more) sstore(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
-
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row0 = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
-      const int col = n0 + wn * 64 + j * 16 + (lane & 15);
-      epilogue_store<EPI>(p.ep, p.M, p.N, row0, col, acc[i][j]);
-    }
+  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
 }
+
+int g_nt_variant = 0;  // 0 auto, 1 two-stage fast, 2 ring 128x128, 3 ring 256x128 (bench/test knob)
 
 template <int EPI>
 int launch_nt_t(const GemmParams& p, hipStream_t s) {
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk);
-  hipLaunchKernelGGL(gemm_nt_kernel<EPI>, grid, dim3(256), 0, s, p);
+  const int tn = (p.N + BN - 1) / BN;
+  const int tiles128 = tn * ((p.M + 127) / 128), tiles256 = tn * ((p.M + 255) / 256);
+  if (p.force_generic || (p.K & 31)) {
+    hipLaunchKernelGGL((gemm_generic_kernel<EPI, false>), dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
+    return 0;
+  }
+  int variant = g_nt_variant;
+  if (p.splitk > 1) variant = 1;
+  else if (variant == 0) variant = 1;  // measured: the 2-stage 128x128 kernel wins at every FACT shape
+  if (variant == 4)
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, 4, 3, 64>), dim3(tiles256), dim3(512), 0, s, p);
+  else if (variant == 3)
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, 4, 6, 32>), dim3(tiles256), dim3(512), 0, s, p);
+  else if (variant == 2)
+    hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, 2, 4, 32>), dim3(tiles128), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL(gemm_nt_fast_kernel<EPI>, dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
   return 0;
 }
 template <int EPI>
 int launch_tn_t(const GemmParams& p, hipStream_t s) {
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.splitk);
-  hipLaunchKernelGGL(gemm_tn_kernel<EPI>, grid, dim3(256), 0, s, p);
+  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.splitk);
+  if ((p.K & 63) == 0 && p.lda >= 8 && p.ldb >= 8 && !p.force_generic)
+    hipLaunchKernelGGL(gemm_tn_fast_kernel<EPI>, grid, dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((gemm_generic_kernel<EPI, true>), grid, dim3(256), 0, s, p);
   return 0;
 }
 
@@ -345,10 +599,13 @@ int check_common(const GemmParams& p, int epi) {
   if (p.splitk < 1) return -3;
   if (p.splitk > 1 && epi != EPI_ATOMIC_F32) return -4;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return -5;
+  if (epi == EPI_HEADS && ((p.ep.dh & 3) || (p.ep.dhp & 3))) return -8;
   return 0;
 }
 
 }  // namespace
+
+void gemm_set_nt_variant(int v) { g_nt_variant = v; }
 
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t s) {
   int rc = check_common(p, epi);

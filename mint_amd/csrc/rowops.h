@@ -11,9 +11,12 @@ int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
 //   dx = dres + LNbwd(dh);  dgamma += sum_rows dh*xhat;  dbeta += sum_rows dh;
 //   dbias_prev += sum_rows dres (bias gradient of the GEMM whose output fed this residual add).
 // dx may alias dres.  dx_bf16 / dbias_prev / dres may be null.
+// `ws` (>= ln_bwd_ws_floats(M, C) floats, or null) holds per-block partial column sums that a second
+// tiny kernel reduces; with ws == null the partials are accumulated with atomics instead.
+size_t ln_bwd_ws_floats(int M, int C);
 int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const float* rstd,
                   const float* gamma, const float* dres, float* dx, bf16_t* dx_bf16, float* dgamma,
-                  float* dbeta, float* dbias_prev, int M, int C, hipStream_t s);
+                  float* dbeta, float* dbias_prev, float* ws, int M, int C, hipStream_t s);
 
 // out[c] += sum_m in[m][c]   (bf16 or f32 input), C % 8 == 0 for bf16, % 4 for f32
 // only columns < Cout are accumulated into out
@@ -37,6 +40,15 @@ int launch_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, fl
 // f32 [R][C] -> bf16 dst [R][ldd] and bf16 dstT [C][ldt] (either may be null)
 int launch_cast_transpose(const float* src, int R, int C, bf16_t* dst, int ldd, bf16_t* dstT, int ldt,
                           hipStream_t s);
+// One launch for a whole table of weight matrices: f32 [R][C] -> bf16 s [R][lds] and t [C][ldt].
+// `descs` lives in device memory; tile_begin is the running sum of 64x64 tile counts.
+struct CastDesc {
+  const float* src;
+  bf16_t* s;
+  bf16_t* t;
+  int R, C, lds, ldt, tiles_x, tile_begin;
+};
+int launch_multi_cast_transpose(const CastDesc* descs, int n, int total_tiles, hipStream_t s);
 // bf16 [R][C] (ld) -> bf16 [C][R] (ldt)
 int launch_transpose_bf16(const bf16_t* src, int ld, int R, int C, bf16_t* dstT, int ldt,
                           hipStream_t s);

@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // Each block handles LN_BWD_ROWS rows (4 waves x LN_BWD_ROWS/4 rows); per-lane column partials
 // of dgamma/dbeta/dbias are reduced across the 4 waves in LDS, then one atomicAdd per column.
-constexpr int LN_BWD_ROWS = 32;
+constexpr int LN_BWD_ROWS = 8;
 
 template <int MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const bf16_t* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* dres, float* dx,
     bf16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dbias_prev, int M, int C) {
+    float* __restrict__ dbias_prev, float* __restrict__ part, int M, int C) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [3][4 waves][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = C >> 2;
@@ -148,10 +148,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       b += red[(1 * 4 + w) * C + c];
       r += red[(2 * 4 + w) * C + c];
     }
-    atomicAdd(dgamma + c, a);
-    atomicAdd(dbeta + c, b);
-    if (dbias_prev && dres) atomicAdd(dbias_prev + c, r);
+    if (part) {  // per-block partial sums, reduced by colreduce_kernel (no same-address atomics)
+      float* pb = part + (size_t)blockIdx.x * 3 * C;
+      pb[c] = a;
+      pb[C + c] = b;
+      pb[2 * C + c] = r;
+    } else {
+      atomicAdd(dgamma + c, a);
+      atomicAdd(dbeta + c, b);
+      if (dbias_prev && dres) atomicAdd(dbias_prev + c, r);
+    }
   }
+}
+
+// out_k[c] += sum over blocks of part[b][k][c], k = 0..2; grid (ceil(3C/256), ceil(nblk/32))
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int nblk, int C,
+                                                        float* __restrict__ o0, float* __restrict__ o1,
+                                                        float* __restrict__ o2) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= 3 * C) return;
+  const int b0 = blockIdx.y * 32, b1 = min(nblk, b0 + 32);
+  float s = 0.f;
+#pragma unroll 8
+  for (int b = b0; b < b1; ++b) s += part[(size_t)b * 3 * C + j];
+  const int k = j / C, c = j - k * C;
+  float* o = (k == 0) ? o0 : (k == 1) ? o1 : o2;
+  if (o) atomicAdd(o + c, s);
 }
 
 // column sums: block = 32 column-chunks x 8 row lanes; each thread owns VEC columns
@@ -279,6 +301,69 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const T* __restrict
   }
 }
 
+// multi-tensor weight-shadow refresh: block -> (tensor, 64x64 tile); float4 reads, 8-byte bf16 stores
+// in both orientations (the transposed one through an LDS tile).
+__global__ __launch_bounds__(256) void multi_cast_transpose_kernel(const CastDesc* __restrict__ descs,
+                                                                   int n) {
+  __shared__ float tile[64][65];
+  __shared__ int which;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n - 1;  // last desc with tile_begin <= blockIdx.x
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].tile_begin <= (int)blockIdx.x) lo = mid;
+      else hi = mid - 1;
+    }
+    which = lo;
+  }
+  __syncthreads();
+  const CastDesc d = descs[which];
+  const int tl = blockIdx.x - d.tile_begin;
+  const int r0 = (tl / d.tiles_x) * 64, c0 = (tl % d.tiles_x) * 64;
+  const int cx = (threadIdx.x & 15) * 4, ry = threadIdx.x >> 4;  // 16 column-quads x 16 rows
+  const bool vec_ok = ((d.C & 3) == 0);
+#pragma unroll
+  for (int rr = ry; rr < 64; rr += 16) {
+    const int r = r0 + rr, c = c0 + cx;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < d.R) {
+      if (vec_ok && c + 3 < d.C) {
+        const float4 f = *reinterpret_cast<const float4*>(d.src + (size_t)r * d.C + c);
+        v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+        bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(d.s + (size_t)r * d.lds + c) = o;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < d.C) {
+            v[j] = d.src[(size_t)r * d.C + c + j];
+            d.s[(size_t)r * d.lds + c + j] = (bf16_t)v[j];
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[rr][cx + j] = v[j];
+  }
+  __syncthreads();
+  // transposed: thread -> column cc, 4 consecutive rows
+  const int rq = (threadIdx.x & 15) * 4, cy = threadIdx.x >> 4;
+#pragma unroll
+  for (int cc = cy; cc < 64; cc += 16) {
+    const int c = c0 + cc, r = r0 + rq;
+    if (c < d.C) {
+      if (r + 3 < d.R) {
+        bf16x4 o = {(bf16_t)tile[rq][cc], (bf16_t)tile[rq + 1][cc], (bf16_t)tile[rq + 2][cc],
+                    (bf16_t)tile[rq + 3][cc]};
+        *reinterpret_cast<bf16x4*>(d.t + (size_t)c * d.ldt + r) = o;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r + j < d.R) d.t[(size_t)c * d.ldt + r + j] = (bf16_t)tile[rq + j][cc];
+      }
+    }
+  }
+}
+
 __global__ void pad_cast_kernel(const float* __restrict__ src, int n, size_t batch_stride, int M,
                                 int F, bf16_t* __restrict__ dst, int Fp) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -353,18 +438,27 @@ int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
   return 0;
 }
 
+size_t ln_bwd_ws_floats(int M, int C) {
+  return (size_t)((M + LN_BWD_ROWS - 1) / LN_BWD_ROWS) * 3 * C;
+}
+
 int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const float* rstd,
                   const float* gamma, const float* dres, float* dx, bf16_t* dx_bf16, float* dgamma,
-                  float* dbeta, float* dbias_prev, int M, int C, hipStream_t s) {
+                  float* dbeta, float* dbias_prev, float* ws, int M, int C, hipStream_t s) {
   if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0) return -1;
   const int grid = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
   const size_t shmem = (size_t)3 * 4 * C * sizeof(float);
   if (C <= 1024) {
     hipLaunchKernelGGL((ln_bwd_kernel<4>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
-                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, M, C);
+                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, ws, M, C);
   } else {
     hipLaunchKernelGGL((ln_bwd_kernel<8>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
-                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, M, C);
+                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, ws, M, C);
+  }
+  if (ws) {
+    dim3 g2((3 * C + 255) / 256, (grid + 31) / 32);
+    hipLaunchKernelGGL(colreduce_kernel, g2, dim3(256), 0, s, ws, grid, C, dgamma, dbeta,
+                       (dres ? dbias_prev : nullptr));
   }
   return 0;
 }
@@ -414,6 +508,12 @@ int launch_cast_transpose(const float* src, int R, int C, bf16_t* dst, int ldd, 
   dim3 grid((C + 63) / 64, (R + 63) / 64);
   hipLaunchKernelGGL((cast_transpose_kernel<float>), grid, dim3(256), 0, s, src, C, R, C, dst, ldd,
                      dstT, ldt);
+  return 0;
+}
+
+int launch_multi_cast_transpose(const CastDesc* descs, int n, int total_tiles, hipStream_t s) {
+  if (n <= 0 || total_tiles <= 0) return 0;
+  hipLaunchKernelGGL(multi_cast_transpose_kernel, dim3(total_tiles), dim3(256), 0, s, descs, n);
   return 0;
 }
 

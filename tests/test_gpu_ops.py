@@ -96,9 +96,17 @@ def _gemm_nt(epi, A, B, M, N, K, out0, out1=None, bias=None, pos=None, seq=0, re
     _sync()
 
 
+@pytest.fixture(params=[0, 1], ids=["fast", "generic"])
+def gemm_path(request):
+    """Run GEMM tests through both the LDS-DMA fast kernels and the register-staged fallback."""
+    L.lib().fact_debug_force_generic_gemm(request.param)
+    yield request.param
+    L.lib().fact_debug_force_generic_gemm(0)
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 136, 72), (5760, 2400, 800),
-                                   (1920, 800, 3072), (333, 225, 800), (64, 800, 256)])
-def test_gemm_nt_bf16(M, N, K):
+                                   (1920, 800, 3072), (333, 225, 800), (64, 800, 256), (130, 132, 96)])
+def test_gemm_nt_bf16(gemm_path, M, N, K):
     g = torch.Generator(device=DEV).manual_seed(1)
     A = _bf(torch.randn(M, K, device=DEV, generator=g))
     B = _bf(torch.randn(N, K, device=DEV, generator=g))
@@ -155,7 +163,7 @@ def test_gemm_nt_epilogues():
 @pytest.mark.parametrize("use_tr", [1, 0])
 @pytest.mark.parametrize("K,Mo,No,splitk", [(128, 128, 128, 1), (512, 256, 384, 2), (5760, 800, 2400, 4),
                                             (1920, 800, 225, 3), (960, 225, 800, 2), (200, 72, 136, 1)])
-def test_gemm_tn(use_tr, K, Mo, No, splitk):
+def test_gemm_tn(gemm_path, use_tr, K, Mo, No, splitk):
     lib = L.lib()
     g = torch.Generator(device=DEV).manual_seed(3)
     lda, ldb = (Mo + 31) // 32 * 32, (No + 31) // 32 * 32

@@ -1,0 +1,87 @@
+"""Micro-benchmark of the NT GEMM kernel variants at the FACT shapes (HIP-event timing)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mint_amd import _lib as L
+
+lib = L.lib()
+dev = "cuda"
+SHAPES = [  # M, N, K, epi
+    (5760, 3072, 800, L.EPI_BIAS_GELU), (5760, 800, 3072, L.EPI_F32_BIAS_RESID), (5760, 2400, 800, L.EPI_BF16),
+    (5760, 800, 800, L.EPI_F32_BIAS_RESID), (5760, 800, 2400, L.EPI_BF16), (5760, 3072, 800, L.EPI_GELU_BWD),
+    (5760, 3072, 800, L.EPI_BF16), (5760, 3072, 3072, L.EPI_BF16), (8192, 8192, 8192, L.EPI_BF16),
+    (3840, 3072, 800, L.EPI_BIAS_GELU), (1920, 3072, 800, L.EPI_BIAS_GELU), (1920, 800, 3072, L.EPI_F32_BIAS_RESID),
+]
+
+
+def run(M, N, K, epi, variant, iters=30):
+    g = torch.Generator(device=dev).manual_seed(0)
+    A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    B = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g)
+    resid = torch.randn(M, N, device=dev, generator=g)
+    pre = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
+    f32 = epi in (L.EPI_F32_BIAS_RESID,)
+    o0 = torch.empty(M, N, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    o1 = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    lib.fact_debug_gemm_nt_variant(variant)
+
+    def launch():
+        L.check(lib.fact_op_gemm_nt(epi, L.ptr(A), K, L.ptr(B), K, M, N, K, L.ptr(o0), N, L.ptr(o1), N, L.ptr(bias),
+                                    None, 0, L.ptr(resid), N, L.ptr(pre), N, L.cur_stream()))
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    ref = A.float() @ B.float().t()
+    if epi == L.EPI_BF16:
+        err = ((o0.float() - ref).norm() / ref.norm()).item()
+    elif epi == L.EPI_F32_BIAS_RESID:
+        err = ((o0 - (ref + bias + resid)).norm() / ref.norm()).item()
+    elif epi == L.EPI_BIAS_GELU:
+        err = ((o0.float() - (ref + bias)).norm() / ref.norm()).item()
+    else:
+        err = float("nan")
+    lib.fact_debug_gemm_nt_variant(0)
+    return us, 2.0 * M * N * K / us / 1e6, err
+
+
+if len(sys.argv) > 1:  # single shape/variant (for rocprofv3 --pmc runs): idx variant iters
+    M, N, K, epi = SHAPES[int(sys.argv[1])]
+    us, tf, err = run(M, N, K, epi, int(sys.argv[2]), int(sys.argv[3]))
+    print("M%d N%d K%d epi%d v%s: %.1f us %.0f TF" % (M, N, K, epi, sys.argv[2], us, tf))
+    sys.exit(0)
+for (M, N, K, epi) in ([] if os.environ.get("TN_ONLY") else SHAPES):
+    line = "M%5d N%5d K%5d epi%d:" % (M, N, K, epi)
+    for v in (1, 3, 4):
+        us, tf, err = run(M, N, K, epi, v)
+        line += "  v%d %7.1fus %6.0fTF err %.1e" % (v, us, tf, err)
+    print(line, flush=True)
+
+print("--- TN (wgrad) ---")
+TN_SHAPES = [(5760, 800, 3072), (5760, 3072, 800), (5760, 800, 2400), (5760, 800, 800), (1920, 800, 3072), (3840, 800, 2400)]
+for (K, Mo, No) in TN_SHAPES:
+    g = torch.Generator(device=dev).manual_seed(0)
+    A = torch.randn(K, Mo, device=dev, generator=g).to(torch.bfloat16)
+    B = torch.randn(K, No, device=dev, generator=g).to(torch.bfloat16)
+    out = torch.zeros(Mo, No, device=dev)
+    line = "K%5d Mo%5d No%5d:" % (K, Mo, No)
+    for splitk in (1, 2, 3, 5, 8):
+        def launch():
+            L.check(lib.fact_op_gemm_tn(L.ptr(A), Mo, L.ptr(B), No, Mo, No, K, L.ptr(out), No, splitk, 1, None,
+                                        L.cur_stream()))
+        for _ in range(2):
+            launch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            launch()
+        e1.record(); e1.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        line += "  sk%d %6.1fus %5.0fTF" % (splitk, us, 2.0 * K * Mo * No / us / 1e6)
+    print(line, flush=True)
