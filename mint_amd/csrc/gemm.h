@@ -45,6 +45,7 @@ struct GemmParams {
   int M, N, K;
   int splitk;
   int force_generic;  // tests: use the register-staged fallback kernel
+  int tile256;        // TN: use the 256x128 ring kernel (M is the 256-tiled dimension)
   EpiParams ep;
 };
 

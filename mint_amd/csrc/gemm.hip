@@ -487,6 +487,119 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast_kernel(const GemmParams p
 }
 
 // ------------------------------------------------------------------------------------------
+// ring TN (wgrad): (WM*64) x 128 output tile, 2*WM waves, 64-deep K stages in an NSTAGE LDS ring,
+// counted vmcnt + raw barrier like the NT ring.  A stage = [64 k][WM*64 m], B stage = [64 k][128 n];
+// rows are 512 / 256 bytes, the 32-byte unit swizzle u ^ f(k) of the fast TN kernel is kept (f only
+// touches the low 3 unit bits, so a 512-byte row swizzles inside each 256-byte half).
+// Requires K % 64 == 0.  Higher arithmetic intensity per LDS-DMA byte than 128x128 (85 vs 64 F/B).
+// ------------------------------------------------------------------------------------------
+template <int ROWB>
+DEVINL bf16x8 tnr_frag(const unsigned char* tile, int ks, int u, int lane) {
+  const int g = lane >> 4, s = lane & 15;
+  bf16x4 r[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    const int k = ks * 32 + g * 8 + hh * 4 + (s >> 2);
+    const int off = k * ROWB + ((u ^ tn_f(k)) << 5) + (s & 3) * 8;
+    r[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off));
+  }
+  bf16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
+  return f;
+}
+
+template <int EPI, int WM, int NSTAGE>
+__global__ __launch_bounds__(WM * 128, 2) void gemm_tn_ring_kernel(const GemmParams p) {
+  constexpr int RBM = WM * 64;
+  constexpr int NW = WM * 2;
+  constexpr int A_ROWB = RBM * 2, B_ROWB = 256;
+  constexpr int A_BYTES = 64 * A_ROWB, B_BYTES = 64 * B_ROWB;
+  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+  constexpr int APW = A_BYTES / 1024 / NW, BPW = B_BYTES / 1024 / NW;
+  constexpr int LPS = APW + BPW;
+  constexpr int DIST = NSTAGE - 1;
+  constexpr int A_RPP = 1024 / A_ROWB, B_RPP = 4;  // rows per DMA piece (A_RPP: 2 for 512-byte rows)
+  static_assert(DIST >= 1 && DIST <= 5 && 4 * LPS < 64 && A_RPP >= 1, "ring geometry");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int tn = (p.N + BN - 1) / BN;
+  int m0, n0, z;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    z = id % p.splitk;
+    const int t = id / p.splitk;
+    n0 = (t % tn) * BN;
+    m0 = (t / tn) * RBM;
+  }
+  int kt_beg, kt_end;
+  split_range(p, z, kt_beg, kt_end);
+  if (kt_beg >= kt_end) return;
+  const int nk = kt_end - kt_beg;
+
+  f32x4 acc[4][4];
+  zero_acc(acc);
+
+  // A piece: A_RPP rows of A_ROWB bytes; lane -> row lane / (A_ROWB/16), chunk position lane % (A_ROWB/16)
+  constexpr int A_CPR = A_ROWB / 16, B_CPR = B_ROWB / 16;
+  int acol[APW], arow[APW], bcol[BPW], brow[BPW];
+#pragma unroll
+  for (int i = 0; i < APW; ++i) {
+    const int k = (wave * APW + i) * A_RPP + lane / A_CPR;
+    const int pp = lane % A_CPR;
+    const int mc = ((((pp >> 1) ^ tn_f(k)) << 1) | (pp & 1)) * 8;
+    arow[i] = k;
+    acol[i] = min(m0 + mc, p.lda - 8);
+  }
+#pragma unroll
+  for (int i = 0; i < BPW; ++i) {
+    const int k = (wave * BPW + i) * B_RPP + lane / B_CPR;
+    const int pp = lane % B_CPR;
+    const int nc = ((((pp >> 1) ^ tn_f(k)) << 1) | (pp & 1)) * 8;
+    brow[i] = k;
+    bcol[i] = min(n0 + nc, p.ldb - 8);
+  }
+  auto stage = [&](int j) {  // j-th K stage of this split
+    unsigned char* base = smem + (j % NSTAGE) * STAGE_BYTES;
+    const size_t k0 = (size_t)(kt_beg + j) * 64;
+#pragma unroll
+    for (int i = 0; i < APW; ++i)
+      glds16(p.A + (k0 + arow[i]) * p.lda + acol[i], base + (wave * APW + i) * 1024);
+#pragma unroll
+    for (int i = 0; i < BPW; ++i)
+      glds16(p.B + (k0 + brow[i]) * p.ldb + bcol[i], base + A_BYTES + (wave * BPW + i) * 1024);
+  };
+
+#pragma unroll
+  for (int s = 0; s < DIST; ++s)
+    if (s < nk) stage(s);
+
+  for (int j = 0; j < nk; ++j) {
+    wait_stages<LPS>(min(DIST - 1, nk - 1 - j));
+    __builtin_amdgcn_s_barrier();
+    if (j + DIST < nk) stage(j + DIST);
+    const unsigned char* As = smem + (j % NSTAGE) * STAGE_BYTES;
+    const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tnr_frag<A_ROWB>(As, ks, wm * 4 + i, lane);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) bfr[jj] = tnr_frag<B_ROWB>(Bs, ks, wn * 4 + jj, lane);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          acc[i][jj] = kSwap<EPI> ? mfma16(bfr[jj], af[i], acc[i][jj]) : mfma16(af[i], bfr[jj], acc[i][jj]);
+    }
+  }
+  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ------------------------------------------------------------------------------------------
 // generic kernels: register-staged, zero-filled bounds (any M, N; K % 8 == 0 for NT)
 // ------------------------------------------------------------------------------------------
 template <int EPI, bool TN>
@@ -585,11 +698,18 @@ int launch_nt_t(const GemmParams& p, hipStream_t s) {
 }
 template <int EPI>
 int launch_tn_t(const GemmParams& p, hipStream_t s) {
-  dim3 grid(((p.N + BN - 1) / BN) * ((p.M + BM - 1) / BM) * p.splitk);
-  if ((p.K & 63) == 0 && p.lda >= 8 && p.ldb >= 8 && !p.force_generic)
-    hipLaunchKernelGGL(gemm_tn_fast_kernel<EPI>, grid, dim3(256), 0, s, p);
-  else
+  const int tn = (p.N + BN - 1) / BN;
+  dim3 grid(tn * ((p.M + BM - 1) / BM) * p.splitk);
+  if ((p.K & 63) == 0 && p.lda >= 8 && p.ldb >= 8 && !p.force_generic) {
+    // g_nt_variant >= 10 selects the 256x128 ring kernel (bench/test knob; engine sets p.tile256)
+    if (p.tile256 || g_nt_variant >= 10)
+      hipLaunchKernelGGL((gemm_tn_ring_kernel<EPI, 4, 3>), dim3(tn * ((p.M + 255) / 256) * p.splitk),
+                         dim3(512), 0, s, p);
+    else
+      hipLaunchKernelGGL(gemm_tn_fast_kernel<EPI>, grid, dim3(256), 0, s, p);
+  } else {
     hipLaunchKernelGGL((gemm_generic_kernel<EPI, true>), grid, dim3(256), 0, s, p);
+  }
   return 0;
 }
 

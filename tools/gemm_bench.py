@@ -64,24 +64,30 @@ for (M, N, K, epi) in ([] if os.environ.get("TN_ONLY") else SHAPES):
     print(line, flush=True)
 
 print("--- TN (wgrad) ---")
-TN_SHAPES = [(5760, 800, 3072), (5760, 3072, 800), (5760, 800, 2400), (5760, 800, 800), (1920, 800, 3072), (3840, 800, 2400)]
+TN_SHAPES = [(5760, 800, 3072), (5760, 3072, 800), (5760, 2400, 800), (5760, 800, 800), (1920, 3072, 800), (3840, 2400, 800)]
 for (K, Mo, No) in TN_SHAPES:
     g = torch.Generator(device=dev).manual_seed(0)
     A = torch.randn(K, Mo, device=dev, generator=g).to(torch.bfloat16)
     B = torch.randn(K, No, device=dev, generator=g).to(torch.bfloat16)
-    out = torch.zeros(Mo, No, device=dev)
-    line = "K%5d Mo%5d No%5d:" % (K, Mo, No)
-    for splitk in (1, 2, 3, 5, 8):
-        def launch():
-            L.check(lib.fact_op_gemm_tn(L.ptr(A), Mo, L.ptr(B), No, Mo, No, K, L.ptr(out), No, splitk, 1, None,
-                                        L.cur_stream()))
-        for _ in range(2):
+    ref = A.float().t() @ B.float()
+    for tv in (0, 10):
+        lib.fact_debug_gemm_nt_variant(tv)
+        line = "K%5d Mo%5d No%5d tv%2d:" % (K, Mo, No, tv)
+        for splitk in (1, 2, 3, 4, 6):
+            out = torch.zeros(Mo, No, device=dev)
+
+            def launch():
+                L.check(lib.fact_op_gemm_tn(L.ptr(A), Mo, L.ptr(B), No, Mo, No, K, L.ptr(out), No, splitk, 1, None,
+                                            L.cur_stream()))
             launch()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            launch()
-        e1.record(); e1.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
-        line += "  sk%d %6.1fus %5.0fTF" % (splitk, us, 2.0 * K * Mo * No / us / 1e6)
-    print(line, flush=True)
+            torch.cuda.synchronize()
+            err = ((out - ref).norm() / ref.norm()).item()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                launch()
+            e1.record(); e1.synchronize()
+            us = e0.elapsed_time(e1) / 20 * 1e3
+            line += "  sk%d %6.1fus %5.0fTF e%.0e" % (splitk, us, 2.0 * K * Mo * No / us / 1e6, err)
+        print(line, flush=True)
+    lib.fact_debug_gemm_nt_variant(0)
