@@ -111,6 +111,18 @@ int fact_set_step(FactHandle* h, int64_t step);
 int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, int B, int audio_len,
                   int steps, float* out, int* steps_done, void* stream);
 
+/* Data-parallel overlap.  During fact_forward_backward the engine calls `cb(user, bucket, offset,
+ * count)` (from the calling thread, while it is still enqueueing work) each time a contiguous
+ * range grads[offset, offset+count) (floats) has all of its producers enqueued; `comm_stream` has
+ * already been made to wait for them, so the host enqueues its sum-all-reduce of that range on
+ * `comm_stream` (RCCL) and it overlaps the remaining backward kernels.  This is the explicit form
+ * of the implicit all-reduce inside optimizer.apply_gradients under MirroredStrategy
+ * (single_task_trainer.py:186-187).  Buckets: head, cross layers L-1..0, audio stack, motion stack.
+ * The caller must make its compute stream wait for `comm_stream` before fact_adam_step.
+ * cb == NULL disables. */
+typedef void (*fact_grad_cb)(void* user, int bucket, size_t offset_floats, size_t count_floats);
+int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* comm_stream);
+
 /* Engine knobs: key "wgrad_tr" (1 = LDS transpose-read wgrad GEMM, 0 = explicit transposes). */
 int fact_set_option(FactHandle* h, const char* key, int value);
 

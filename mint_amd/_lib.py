@@ -35,6 +35,9 @@ class FactArenas(C.Structure):
                 ("adam_v", C.c_void_p)]
 
 
+# fact_grad_cb: void (*)(void* user, int bucket, size_t offset_floats, size_t count_floats)
+GRAD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t)
+
 # name -> (restype, argtypes); kept in sync with include/fact_hip.h (tests check every symbol)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
@@ -53,6 +56,7 @@ SIGNATURES = {
     "fact_set_step": (_i, [_vp, C.c_int64]),
     "fact_infer_ar": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
     "fact_set_option": (_i, [_vp, C.c_char_p, _i]),
+    "fact_set_grad_callback": (_i, [_vp, GRAD_CB, _vp, _vp]),
     "fact_op_gemm_nt": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i,
                              _vp, _i, _vp]),
     "fact_op_gemm_tn": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),

@@ -141,6 +141,11 @@ struct FactHandle {
   std::vector<hipEvent_t> ev;
   size_t ev_i = 0;
   hipEvent_t ev_dpre_free = nullptr, ev_dqkv_free = nullptr;  // side-stream readers of dpre / dqkv done
+  // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
+  fact_grad_cb cb = nullptr;
+  void* cb_user = nullptr;
+  hipStream_t cb_stream = nullptr;
+  int cb_bucket = 0;
 };
 
 namespace {
@@ -599,6 +604,18 @@ int model_forward_hidden(FactHandle* h, const float* motion, size_t m_stride, co
   return 0;
 }
 
+size_t tensor_end(const Tensor& t) { return rups(t.off + t.numel(), 64); }
+
+// Every kernel that contributes to grads[beg, end) has been enqueued (main + side stream): make the
+// caller's communication stream wait for them and tell the host, which enqueues the all-reduce of
+// that range there.  Nothing blocks; the collective overlaps the rest of the backward pass.
+void notify_grads(FactHandle* h, size_t beg, size_t end, hipStream_t s) {
+  if (!h->cb) return;
+  stream_after(h, s, h->cb_stream);
+  if (side_of(h, s) != s) stream_after(h, h->side, h->cb_stream);
+  h->cb(h->cb_user, h->cb_bucket++, beg, end - beg);
+}
+
 int check_batch(FactHandle* h, int B) {
   if (!h) return fail(-1, "null handle");
   if (B <= 0 || B > h->max_batch)
@@ -744,6 +761,14 @@ int fact_refresh_weights(FactHandle* h, void* stream) {
   return refresh_all(h, (hipStream_t)stream);
 }
 
+int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* comm_stream) {
+  if (!h) return fail(-1, "null handle");
+  h->cb = cb;
+  h->cb_user = user;
+  h->cb_stream = (hipStream_t)comm_stream;
+  return 0;
+}
+
 int fact_set_option(FactHandle* h, const char* key, int value) {
   if (!h || !key) return fail(-1, "null argument");
   if (!strcmp(key, "wgrad_tr")) {
@@ -805,12 +830,21 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
     g.ep.out0 = h->dx; g.ep.ldo0 = d; g.ep.out1 = h->dx16; g.ep.ldo1 = d;
     CHK(launch_gemm_nt(EPI_F32_BF16, g, s));
   }
-  for (int l = cr.L - 1; l >= 0; --l) CHK(layer_backward(h, cr, l, B, h->dx, h->dx16, s));
+  // Gradient buckets are contiguous arena ranges reported in the order they become final:
+  // head, cross layers L-1..0, audio stack, motion stack (fact_set_grad_callback).
+  h->cb_bucket = 0;
+  notify_grads(h, h->head.w.off, tensor_end(h->head_b), s);
+  for (int l = cr.L - 1; l >= 0; --l) {
+    CHK(layer_backward(h, cr, l, B, h->dx, h->dx16, s));
+    notify_grads(h, cr.lp[l].ln1_g.off, tensor_end(cr.lp[l].b2), s);
+  }
   CHK(launch_split_grad(h->dx, B, mo.n, au.n, d, h->dxm, h->dxm16, h->dxa, h->dxa16, s));
   for (int l = au.L - 1; l >= 0; --l) CHK(layer_backward(h, au, l, B, h->dxa, h->dxa16, s));
   CHK(embed_backward(h, au, B, h->dxa, h->dxa16, s));
+  notify_grads(h, au.L ? au.lp[0].ln1_g.off : au.pos.off, tensor_end(au.emb_b), s);
   for (int l = mo.L - 1; l >= 0; --l) CHK(layer_backward(h, mo, l, B, h->dxm, h->dxm16, s));
   CHK(embed_backward(h, mo, B, h->dxm, h->dxm16, s));
+  notify_grads(h, mo.L ? mo.lp[0].ln1_g.off : mo.pos.off, tensor_end(mo.emb_b), s);
   if (side_of(h, s) != s) stream_after(h, h->side, s);  // join: the caller's stream sees all gradients
   h->ev_dpre_free = nullptr;
   h->ev_dqkv_free = nullptr;

@@ -70,6 +70,8 @@ class FACTModel:
         self._feat = {"motion": self.feature_to_params["motion"]["feature_dim"],
                       "audio": self.feature_to_params["audio"]["feature_dim"]}
         self._loss_buf = None
+        self._grad_cb = None
+        self._grad_cb_args = None
 
     # ------------------------------------------------------------------------------------------
     def _cfg_struct(self):
@@ -136,6 +138,8 @@ class FACTModel:
         L.check(lib.fact_set_step(self._h, int(self.global_step)))
         L.check(lib.fact_refresh_weights(self._h, L.cur_stream()))
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self._device)
+        if self._grad_cb_args is not None:  # handle was re-created: re-register the bucket callback
+            self.set_grad_callback(*self._grad_cb_args)
 
     def _init_parameters(self):
         """Reference initialisers: glorot_uniform Dense kernels and zero biases
@@ -281,6 +285,20 @@ class FACTModel:
     def sync_weights(self):
         self._require_built()
         L.check(L.lib().fact_refresh_weights(self._h, L.cur_stream()))
+
+    def set_grad_callback(self, fn, comm_stream):
+        """Register `fn(bucket, offset, count)` to be called during forward_backward whenever the
+        gradient range grad_arena[offset:offset+count] is final on `comm_stream` (a torch.cuda.Stream);
+        fn=None disables.  See include/fact_hip.h fact_set_grad_callback."""
+        self._require_built()
+        self._grad_cb_args = None if fn is None else (fn, comm_stream)
+        if fn is None:
+            self._grad_cb = L.GRAD_CB(0)
+            L.check(L.lib().fact_set_grad_callback(self._h, self._grad_cb, None, None))
+            return
+        self._grad_cb = L.GRAD_CB(lambda user, bucket, off, cnt: fn(int(bucket), int(off), int(cnt)))
+        L.check(L.lib().fact_set_grad_callback(self._h, self._grad_cb, None,
+                                               C.c_void_p(comm_stream.cuda_stream)))
 
     def set_option(self, key, value):
         self._require_built()

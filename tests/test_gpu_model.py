@@ -216,3 +216,46 @@ def test_fact_v5_forward_and_grads_vs_oracle():
             assert c > 0.98, "%s cos %.4f" % (name, c)
     # all-reduce friendly invariant: gradients are finite everywhere
     assert torch.isfinite(model.grad_arena).all()
+
+
+def test_overlapped_allreduce_callback_path_single_rank():
+    """Bucket-ready callbacks + RCCL on a side stream (world_size 1 here: the multi-GPU path with the
+    same code; the sum over one replica must leave gradients/updates identical to the plain path)."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cfg = O.TINY_CFG
+        batch = gpu_batch(O.synthetic_batch(cfg, 4, 8, seed=2))
+        results = []
+        for overlap in (False, True):
+            model = model_builder.build(make_config(cfg), True)
+            seen = []
+            tr = SingleTaskTrainer([batch] * 3, "target", model, optimizer=Adam(1e-3),
+                                   overlap_grad_allreduce=overlap)
+            it = iter([batch] * 3)
+            losses = [float(tr.train_step(it)) for _ in range(3)]
+            if overlap:
+                assert tr._reducer is not None
+                orig = tr._reducer._on_bucket
+                tr._reducer.model.set_grad_callback(lambda b, o, c: (seen.append((b, o, c)), orig(b, o, c)),
+                                                    tr._reducer.comm)
+                batch2 = dict(batch)
+                tgt = batch2.pop("target")
+                model.forward_backward(batch2, tgt)
+                tr._reducer.finish()
+                # buckets: head, cross L-1..0, audio stack, motion stack; contiguous, cover the arena once
+                assert [b for b, _, _ in seen] == list(range(1 + cfg["cross"]["layers"] + 2))
+                covered = sorted((o, o + c) for _, o, c in seen)
+                assert covered[0][0] == 0 and covered[-1][1] == model.grad_arena.numel()
+                assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+                model.grad_arena.zero_()
+            torch.cuda.synchronize()
+            results.append((losses, torch.cat([v.flatten() for v in model.trainable_variables]).cpu()))
+        assert results[0][0] == pytest.approx(results[1][0], rel=1e-5)
+        assert torch.allclose(results[0][1], results[1][1], rtol=1e-4, atol=1e-6)
+    finally:
+        dist.destroy_process_group()
