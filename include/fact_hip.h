@@ -155,6 +155,8 @@ int fact_probe_mfma(const float* a_regs, const float* b_regs, float* d_regs, voi
 int fact_probe_tr(const float* lds_vals, int n, const int* byte_addrs, float* out, void* stream);
 /* Test knob: route every GEMM through the register-staged generic kernels (process-global). */
 int fact_debug_force_generic_gemm(int on);
+/* Test knob: 1 = use the tiled (streaming) attention kernels even when the LDS-resident ones fit. */
+int fact_debug_attn_force_tiled(int on);
 /* Test/bench knob: NT GEMM kernel choice (0 auto, 1 two-stage 128x128, 2 ring 128x128, 3 ring 256x128). */
 int fact_debug_gemm_nt_variant(int v);
 

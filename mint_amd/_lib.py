@@ -70,6 +70,7 @@ SIGNATURES = {
     "fact_probe_tr": (_i, [_vp, _i, _vp, _vp, _vp]),
     "fact_debug_force_generic_gemm": (_i, [_i]),
     "fact_debug_gemm_nt_variant": (_i, [_i]),
+    "fact_debug_attn_force_tiled": (_i, [_i]),
 }
 
 _LIB = None

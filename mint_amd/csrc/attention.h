@@ -30,3 +30,4 @@ struct AttnParams {
 
 int launch_attn_fwd(const AttnParams& p, hipStream_t s);
 int launch_attn_bwd(const AttnParams& p, hipStream_t s);  // prep + dQ + dKdV
+void attn_set_force_tiled(int on);  // test knob: 1 = tiled (streaming) kernels even when the LDS-resident ones fit

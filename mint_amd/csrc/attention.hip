@@ -413,6 +413,421 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
   }
 }
 
+// =============================================================================================
+// LDS-resident family (the fast path for FACT's sequence lengths, n <= 512)
+// ---------------------------------------------------------------------------------------------
+// One workgroup per (batch, head) with one wave per 32 query (or key) rows.  The operands every
+// wave needs for ALL tiles - K and V (forward, dQ) or Q and dO (dK/dV) of this head - are brought
+// into LDS ONCE with 16-byte LDS-DMA (global_load_lds_dwordx4) and stay resident: 360x96 bf16 is
+// 69 KiB per operand, two fit in the 160 KiB LDS.  After one vmcnt(0)+barrier the waves run their
+// whole tile loop barrier-free (MFMA / exp / LDS-read streams of the 3 waves per SIMD interleave).
+//
+// LDS images (no padding, DMA writes them linearly, the swizzle is applied to the SOURCE address):
+//   img96: [rows][DHP] bf16, 16-byte chunk c of row r at position c ^ G[(r>>2)&3], G = {0,2,3,1}
+//          -> ds_read_b128 row fragments are bank-conflict free; token-contracting fragments come
+//          from the same image through ds_read_b64_tr_b16.
+//   img80: [rows][DH] bf16 un-swizzled (forward V: only transpose reads; 160-byte rows already
+//          spread 8 consecutive rows over all 64 banks).
+// =============================================================================================
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+DEVINL int res_g(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+
+// DMA `rows` rows of a token-major [.][DHP] buffer into an LDS image with CPR 16-byte chunks per
+// row (CPR*8 <= DHP columns are kept); SWZ selects the img96 swizzle.
+template <int DHP, int CPR, bool SWZ>
+DEVINL void res_load(unsigned char* img, const bf16_t* src, int rows, int wave, int nwaves, int lane) {
+  const int total = rows * CPR;
+  const int pieces = (total + 63) >> 6;
+  for (int pi = wave; pi < pieces; pi += nwaves) {
+    const int q = pi * 64 + lane;
+    if (q < total) {
+      const int r = q / CPR, cp = q - r * CPR;
+      const int c = SWZ ? (cp ^ res_g(r)) : cp;
+      __builtin_amdgcn_global_load_lds((gbl_cvoid*)(src + (size_t)r * DHP + c * 8), (lds_void*)(img + pi * 1024), 16,
+                                       0, 0);
+    }
+  }
+}
+
+// row fragment (A or B operand, contraction over the head dim) from an img96
+template <int DHP>
+DEVINL bf16x8 res_frag_row(const unsigned char* img, int row, int kd, int lane) {
+  const int r = row + (lane & 15);
+  const int c = kd * 4 + (lane >> 4);
+  return *reinterpret_cast<const bf16x8*>(img + r * (DHP * 2) + ((c ^ res_g(r)) << 4));
+}
+// token-contracting fragment [16 dims of tile dt][32 tokens from tok0] from an img96 (slot convention
+// as frag_tr above)
+template <int DHP>
+DEVINL bf16x8 res_frag_tr96(const unsigned char* img, int tok0, int dt, int lane) {
+  const int g = lane >> 4, s = lane & 15;
+  const int r = tok0 + g * 4 + (s >> 2);
+  const int off = r * (DHP * 2) + (((dt * 2 + ((s & 3) >> 1)) ^ res_g(r)) << 4) + (s & 1) * 8;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off + 16 * DHP * 2));
+  return cat4(lo, hi);
+}
+// same from an un-swizzled img80 ([rows][DH])
+template <int DH>
+DEVINL bf16x8 res_frag_tr80(const unsigned char* img, int tok0, int dt, int lane) {
+  const int g = lane >> 4, s = lane & 15;
+  const int off = (tok0 + g * 4 + (s >> 2)) * (DH * 2) + (dt * 16 + (s & 3) * 4) * 2;
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off));
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off + 16 * DH * 2));
+  return cat4(lo, hi);
+}
+
+template <int DH>
+__global__ __launch_bounds__(768) void attn_fwd_res_kernel(const AttnParams p) {
+  using G = Geo<DH>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, g = lane >> 4;
+  const int bh = blockIdx.x;
+  const int rows = (p.n + 31) & ~31;
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + (((size_t)rows * G::DHP * 2 + 1023) & ~(size_t)1023);
+  const size_t row_base = (size_t)bh * p.NP * G::DHP;
+  res_load<G::DHP, G::DHP / 8, true>(Kimg, p.krow + row_base, rows, wave, nw, lane);
+  res_load<G::DHP, DH / 8, false>(Vimg, p.vrow + row_base, rows, wave, nw, lane);
+
+  const int q0 = wave * 32;
+  bf16x8 Qf[2][G::KD];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int kd = 0; kd < G::KD; ++kd)
+      Qf[qs][kd] = *reinterpret_cast<const bf16x8*>(
+          p.qrow + row_base + (size_t)(q0 + qs * 16 + (lane & 15)) * G::DHP + kd * 32 + g * 8);
+  f32x4 O[2][G::ND];
+  float m[2], l[2];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    m[qs] = -INFINITY;
+    l[qs] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < G::ND; ++dt) O[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sc = p.scale * LOG2E;
+  const int nkt = rows >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x4 s[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kd = 0; kd < G::KD; ++kd) {
+        const bf16x8 kf = res_frag_row<G::DHP>(Kimg, kt * 32 + ks * 16, kd, lane);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = mfma16(kf, Qf[qs][kd], s[ks][qs]);
+      }
+    // padded keys only exist in the last tile (wave-uniform branch); the softmax scale is folded
+    // into the exponent below: exp2(s*sc - m) with m tracked in the scaled domain
+    if (kt == nkt - 1 && (p.n & 31)) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = (kt * 32 + ks * 16 + g * 4 + r) < p.n;
+#pragma unroll
+          for (int qs = 0; qs < 2; ++qs) s[ks][qs][r] = valid ? s[ks][qs][r] : -INFINITY;
+        }
+    }
+    bf16x8 pb[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      float mx = fmaxf(fmaxf(fmaxf(s[0][qs][0], s[0][qs][1]), fmaxf(s[0][qs][2], s[0][qs][3])),
+                       fmaxf(fmaxf(s[1][qs][0], s[1][qs][1]), fmaxf(s[1][qs][2], s[1][qs][3])));
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m[qs], mx * sc);  // sc > 0: max commutes with the scale
+      f32x4 p0, p1;
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p0[r] = __builtin_amdgcn_exp2f(fmaf(s[0][qs][r], sc, -mn));
+        p1[r] = __builtin_amdgcn_exp2f(fmaf(s[1][qs][r], sc, -mn));
+        ls += p0[r] + p1[r];
+      }
+      if (__any(mn > m[qs])) {  // exact online-softmax rescale, skipped (wave-uniformly) when no row max grew
+        const float alpha = __builtin_amdgcn_exp2f(m[qs] - mn);
+        l[qs] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt) {
+          O[qs][dt][0] *= alpha; O[qs][dt][1] *= alpha; O[qs][dt][2] *= alpha; O[qs][dt][3] *= alpha;
+        }
+      }
+      l[qs] += ls;
+      m[qs] = mn;
+      pb[qs] = pack8(p0, p1);
+    }
+#pragma unroll
+    for (int dt = 0; dt < G::ND; ++dt) {
+      const bf16x8 vf = res_frag_tr80<DH>(Vimg, kt * 32, dt, lane);
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) O[qs][dt] = mfma16(vf, pb[qs], O[qs][dt]);
+    }
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    float lt = l[qs];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    const float inv = 1.0f / lt;
+    const int t = q0 + qs * 16 + (lane & 15);
+    if (g == 0 && t < p.NP) p.lse2[(size_t)bh * p.NP + t] = m[qs] + __log2f(lt);
+    if (t < p.n) {
+      bf16_t* orow = p.out + ((size_t)b * p.n + t) * p.hid + h * DH + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < G::ND; ++dt) {
+        bf16x4 o = {(bf16_t)(O[qs][dt][0] * inv), (bf16_t)(O[qs][dt][1] * inv),
+                    (bf16_t)(O[qs][dt][2] * inv), (bf16_t)(O[qs][dt][3] * inv)};
+        *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
+      }
+    }
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(768) void attn_bwd_dq_res_kernel(const AttnParams p) {
+  using G = Geo<DH>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, g = lane >> 4;
+  const int bh = blockIdx.x;
+  const int rows = (p.n + 31) & ~31;
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + (((size_t)rows * G::DHP * 2 + 1023) & ~(size_t)1023);
+  const size_t row_base = (size_t)bh * p.NP * G::DHP;
+  res_load<G::DHP, G::DHP / 8, true>(Kimg, p.krow + row_base, rows, wave, nw, lane);
+  res_load<G::DHP, G::DHP / 8, true>(Vimg, p.vrow + row_base, rows, wave, nw, lane);
+
+  const int q0 = wave * 32;
+  bf16x8 Qf[2][G::KD], dOf[2][G::KD];
+  float L2q[2], Dq[2];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    const int q = q0 + qs * 16 + (lane & 15);
+#pragma unroll
+    for (int kd = 0; kd < G::KD; ++kd) {
+      const size_t off = row_base + (size_t)q * G::DHP + kd * 32 + g * 8;
+      Qf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.qrow + off);
+      dOf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.dorow + off);
+    }
+    L2q[qs] = p.lse2[(size_t)bh * p.NP + q];
+    Dq[qs] = p.dsum[(size_t)bh * p.NP + q];
+  }
+  f32x4 dQ[2][G::ND];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int dt = 0; dt < G::ND; ++dt) dQ[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sc = p.scale * LOG2E;
+  const int nkt = rows >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+    f32x4 s[2][2], dp[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kd = 0; kd < G::KD; ++kd) {
+        const bf16x8 kf = res_frag_row<G::DHP>(Kimg, kt * 32 + ks * 16, kd, lane);
+        const bf16x8 vf = res_frag_row<G::DHP>(Vimg, kt * 32 + ks * 16, kd, lane);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+          s[ks][qs] = mfma16(kf, Qf[qs][kd], s[ks][qs]);
+          dp[ks][qs] = mfma16(vf, dOf[qs][kd], dp[ks][qs]);
+        }
+      }
+    bf16x8 dsb[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      f32x4 d0, d1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool v0 = (kt * 32 + g * 4 + r) < p.n;
+        const bool v1 = (kt * 32 + 16 + g * 4 + r) < p.n;
+        const float p0 = v0 ? __builtin_amdgcn_exp2f(fmaf(s[0][qs][r], sc, -L2q[qs])) : 0.f;
+        const float p1 = v1 ? __builtin_amdgcn_exp2f(fmaf(s[1][qs][r], sc, -L2q[qs])) : 0.f;
+        d0[r] = p0 * (dp[0][qs][r] - Dq[qs]);
+        d1[r] = p1 * (dp[1][qs][r] - Dq[qs]);
+      }
+      dsb[qs] = pack8(d0, d1);
+    }
+#pragma unroll
+    for (int dt = 0; dt < G::ND; ++dt) {
+      const bf16x8 ktf = res_frag_tr96<G::DHP>(Kimg, kt * 32, dt, lane);
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) dQ[qs][dt] = mfma16(ktf, dsb[qs], dQ[qs][dt]);
+    }
+  }
+  const int b = bh / p.H, h = bh - b * p.H;
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    const int t = q0 + qs * 16 + (lane & 15);
+    if (t < p.n) {
+      bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * (3 * p.hid) + h * DH + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < G::ND; ++dt) {
+        bf16x4 o = {(bf16_t)(dQ[qs][dt][0] * p.scale), (bf16_t)(dQ[qs][dt][1] * p.scale),
+                    (bf16_t)(dQ[qs][dt][2] * p.scale), (bf16_t)(dQ[qs][dt][3] * p.scale)};
+        *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
+      }
+    }
+  }
+}
+
+// dK/dV: 8 waves (2 per SIMD, 256-VGPR budget: K/V fragments + both accumulators stay in registers);
+// the 32-key slots of the head are dealt round-robin, so with 12 slots every SIMD gets 3.
+template <int DH>
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_res_kernel(const AttnParams p) {
+  using G = Geo<DH>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, g = lane >> 4;
+  const int bh = blockIdx.x;
+  const int rows = (p.n + 31) & ~31;
+  const size_t img_bytes = ((size_t)rows * G::DHP * 2 + 1023) & ~(size_t)1023;
+  unsigned char* Qimg = smem;
+  unsigned char* dOimg = smem + img_bytes;
+  float* L2s = reinterpret_cast<float*>(smem + 2 * img_bytes);
+  float* Dss = L2s + rows;
+  const size_t row_base = (size_t)bh * p.NP * G::DHP;
+  res_load<G::DHP, G::DHP / 8, true>(Qimg, p.qrow + row_base, rows, wave, nw, lane);
+  res_load<G::DHP, G::DHP / 8, true>(dOimg, p.dorow + row_base, rows, wave, nw, lane);
+  for (int i = tid; i < rows; i += blockDim.x) {
+    L2s[i] = p.lse2[(size_t)bh * p.NP + i];
+    Dss[i] = p.dsum[(size_t)bh * p.NP + i];
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sc = p.scale * LOG2E;
+  const int nqt = rows >> 5;
+  const int b = bh / p.H, h = bh - b * p.H;
+  for (int slot = wave; slot < nqt; slot += nw) {
+    const int key0 = slot * 32;
+    bf16x8 Kf[2][G::KD], Vf[2][G::KD];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kd = 0; kd < G::KD; ++kd) {
+        const size_t off = row_base + (size_t)(key0 + ks * 16 + (lane & 15)) * G::DHP + kd * 32 + g * 8;
+        Kf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.krow + off);
+        Vf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.vrow + off);
+      }
+    f32x4 dK[2][G::ND], dV[2][G::ND];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < G::ND; ++dt) {
+        dK[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dV[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    bool kvalid[2];
+    kvalid[0] = (key0 + (lane & 15)) < p.n;
+    kvalid[1] = (key0 + 16 + (lane & 15)) < p.n;
+    for (int qt = 0; qt < nqt; ++qt) {
+      f32x4 s[2][2], dp[2][2];  // [qsub][ksub]
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s[qs][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[qs][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int kd = 0; kd < G::KD; ++kd) {
+          const bf16x8 qf = res_frag_row<G::DHP>(Qimg, qt * 32 + qs * 16, kd, lane);
+          const bf16x8 df = res_frag_row<G::DHP>(dOimg, qt * 32 + qs * 16, kd, lane);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s[qs][ks] = mfma16(qf, Kf[ks][kd], s[qs][ks]);
+            dp[qs][ks] = mfma16(df, Vf[ks][kd], dp[qs][ks]);
+          }
+        }
+      const f32x4 l2a = *reinterpret_cast<const f32x4*>(&L2s[qt * 32 + g * 4]);
+      const f32x4 l2b = *reinterpret_cast<const f32x4*>(&L2s[qt * 32 + 16 + g * 4]);
+      const f32x4 dda = *reinterpret_cast<const f32x4*>(&Dss[qt * 32 + g * 4]);
+      const f32x4 ddb = *reinterpret_cast<const f32x4*>(&Dss[qt * 32 + 16 + g * 4]);
+      bf16x8 pb[2], dsb[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 p0, p1, d0, d1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          p0[r] = kvalid[ks] ? __builtin_amdgcn_exp2f(fmaf(s[0][ks][r], sc, -l2a[r])) : 0.f;
+          p1[r] = kvalid[ks] ? __builtin_amdgcn_exp2f(fmaf(s[1][ks][r], sc, -l2b[r])) : 0.f;
+          d0[r] = p0[r] * (dp[0][ks][r] - dda[r]);
+          d1[r] = p1[r] * (dp[1][ks][r] - ddb[r]);
+        }
+        pb[ks] = pack8(p0, p1);
+        dsb[ks] = pack8(d0, d1);
+      }
+#pragma unroll
+      for (int dt = 0; dt < G::ND; ++dt) {
+        const bf16x8 dof = res_frag_tr96<G::DHP>(dOimg, qt * 32, dt, lane);
+        const bf16x8 qtf = res_frag_tr96<G::DHP>(Qimg, qt * 32, dt, lane);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          dV[ks][dt] = mfma16(dof, pb[ks], dV[ks][dt]);
+          dK[ks][dt] = mfma16(qtf, dsb[ks], dK[ks][dt]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int t = key0 + ks * 16 + (lane & 15);
+      if (t < p.n) {
+        bf16_t* krow_o = p.dqkv + ((size_t)b * p.n + t) * (3 * p.hid) + p.hid + h * DH + g * 4;
+        bf16_t* vrow_o = krow_o + p.hid;
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt) {
+          bf16x4 ok = {(bf16_t)(dK[ks][dt][0] * p.scale), (bf16_t)(dK[ks][dt][1] * p.scale),
+                       (bf16_t)(dK[ks][dt][2] * p.scale), (bf16_t)(dK[ks][dt][3] * p.scale)};
+          bf16x4 ov = {(bf16_t)dV[ks][dt][0], (bf16_t)dV[ks][dt][1], (bf16_t)dV[ks][dt][2],
+                       (bf16_t)dV[ks][dt][3]};
+          *reinterpret_cast<bf16x4*>(krow_o + dt * 16) = ok;
+          *reinterpret_cast<bf16x4*>(vrow_o + dt * 16) = ov;
+        }
+      }
+    }
+  }
+}
+
+int g_attn_force_tiled = 0;  // test knob: 1 = always use the tiled (streaming) kernels
+
+// LDS bytes of the resident kernels for n tokens; 0 = does not fit -> tiled kernels
+template <int DH>
+size_t res_lds_bytes(int n, int which /*0 fwd, 1 dq, 2 dkdv*/) {
+  using G = Geo<DH>;
+  const size_t rows = (size_t)((n + 31) & ~31);
+  const size_t img = (rows * G::DHP * 2 + 1023) & ~(size_t)1023;
+  size_t b = 0;
+  if (which == 0) b = img + ((rows * DH * 2 + 1023) & ~(size_t)1023);
+  else if (which == 1) b = 2 * img;
+  else b = 2 * img + rows * 8;
+  if (rows > 384 || b > 160 * 1024 || g_attn_force_tiled) return 0;  // <= 12 waves (768 threads)
+  return b;
+}
+
 int check(const AttnParams& p) {
   if (p.B <= 0 || p.H <= 0 || p.n <= 0) return -1;
   if (p.NP % 128 != 0 || p.NP < p.n) return -2;
@@ -421,8 +836,27 @@ int check(const AttnParams& p) {
   return 0;
 }
 
+template <typename K>
+int allow_big_lds(K kernel, bool* done) {
+  if (!*done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return -20;
+    *done = true;
+  }
+  return 0;
+}
+
 template <int DH>
 int fwd_t(const AttnParams& p, hipStream_t s) {
+  const size_t lds = res_lds_bytes<DH>(p.n, 0);
+  if (lds) {
+    static bool attr = false;
+    if (int rc = allow_big_lds(attn_fwd_res_kernel<DH>, &attr)) return rc;
+    const int nw = ((p.n + 31) & ~31) / 32;
+    hipLaunchKernelGGL(attn_fwd_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds, s, p);
+    return 0;
+  }
   dim3 grid((p.n + 127) / 128, p.B * p.H);
   hipLaunchKernelGGL(attn_fwd_kernel<DH>, grid, dim3(256), 0, s, p);
   return 0;
@@ -431,13 +865,29 @@ template <int DH>
 int bwd_t(const AttnParams& p, hipStream_t s) {
   const int total = p.B * p.H * p.NP;
   hipLaunchKernelGGL(attn_bwd_prep_kernel<DH>, dim3((total + 255) / 256), dim3(256), 0, s, p);
+  const size_t lds1 = res_lds_bytes<DH>(p.n, 1), lds2 = res_lds_bytes<DH>(p.n, 2);
+  const int nw = ((p.n + 31) & ~31) / 32;
   dim3 grid((p.n + 127) / 128, p.B * p.H);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
-  hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
+  if (lds1) {
+    static bool attr = false;
+    if (int rc = allow_big_lds(attn_bwd_dq_res_kernel<DH>, &attr)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
+  }
+  if (lds2) {
+    static bool attr = false;
+    if (int rc = allow_big_lds(attn_bwd_dkdv_res_kernel<DH>, &attr)) return rc;
+    hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel<DH>, dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
+  }
   return 0;
 }
 
 }  // namespace
+
+void attn_set_force_tiled(int on) { g_attn_force_tiled = on; }
 
 int launch_attn_fwd(const AttnParams& p, hipStream_t s) {
   int rc = check(p);

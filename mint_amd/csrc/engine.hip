@@ -135,6 +135,8 @@ struct FactHandle {
   size_t ar_motion_floats = 0;
   int64_t step = 0;
   int wgrad_tr = 1;
+  int wgrad_slab = 1;
+  float* slab = nullptr;  // split-K partial slabs of the wgrad GEMM running on the side stream
   // second stream: wgrad GEMMs run beside the dgrad chain, the audio encoder beside the motion encoder
   int use_side = 1;
   hipStream_t side = nullptr;
@@ -350,6 +352,7 @@ void layout_work(FactHandle* h, Bump& b) {
     h->dorow = b.take<bf16_t>(rowmax);
     h->dsum = b.take<float>(lsemax);
     h->ln_ws = b.take<float>(ln_bwd_ws_floats((int)Mc, d));
+    h->slab = b.take<float>((size_t)6 * rups((size_t)d * (ffmax > 3 * d ? ffmax : 3 * d), 4));
     const size_t wide = (size_t)(ffmax > 3 * d ? ffmax : 3 * d);
     h->tA = b.take<bf16_t>(wide * rups(Mc, 8));
     h->tB = b.take<bf16_t>(wide * rups(Mc, 8));
@@ -423,6 +426,16 @@ int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int 
   if (h->wgrad_tr) {
     GemmParams p = gp(A, lda, B, ldb, Mo, No, K);
     p.splitk = splitk;
+    if (h->wgrad_slab && ldo == No) {
+      // split-K partials as plain float4 stores into per-split slabs + one streaming reduce
+      // (fp32 atomics to the fabric cost more than the whole K loop at these sizes)
+      const size_t stride = rups((size_t)Mo * No, 4);
+      p.ep.out0 = h->slab;
+      p.ep.ldo0 = No;
+      p.ep.slab_stride = stride;
+      CHK(launch_gemm_tn(EPI_F32_SLAB, p, s));
+      return launch_slab_reduce(h->slab, stride, splitk, out, (size_t)Mo * No, s);
+    }
     p.ep.out0 = out;
     p.ep.ldo0 = ldo;
     return launch_gemm_tn(EPI_ATOMIC_F32, p, s);
@@ -775,6 +788,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     h->wgrad_tr = value;
     return 0;
   }
+  if (!strcmp(key, "wgrad_slab")) {
+    h->wgrad_slab = value;
+    return 0;
+  }
   if (!strcmp(key, "side_stream")) {
     h->use_side = value;
     return 0;
@@ -943,6 +960,15 @@ int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int
 int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int No, int K,
                     float* out, int ldo, int splitk, int use_tr, void* scratch, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  if (use_tr == 2) {  // slab mode: scratch >= splitk * round4(Mo*No) floats
+    if (!scratch || ldo != No) return fail(-1, "slab mode needs scratch and ldo == No");
+    GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)B, ldb, Mo, No, K);
+    const size_t stride = rups((size_t)Mo * No, 4);
+    p.splitk = splitk; p.ep.out0 = scratch; p.ep.ldo0 = No; p.ep.slab_stride = stride;
+    CHK(launch_gemm_tn(EPI_F32_SLAB, p, s));
+    CHK(launch_slab_reduce((const float*)scratch, stride, splitk, out, (size_t)Mo * No, s));
+    return 0;
+  }
   if (use_tr) {
     GemmParams p = gp((const bf16_t*)A, lda, (const bf16_t*)B, ldb, Mo, No, K);
     p.splitk = splitk; p.ep.out0 = out; p.ep.ldo0 = ldo;
@@ -1050,6 +1076,10 @@ int fact_op_attention(const void* qkv, int B, int H, int n, int dh, float scale,
 
 int fact_debug_force_generic_gemm(int on) {
   g_force_generic_gemm = on;
+  return 0;
+}
+int fact_debug_attn_force_tiled(int on) {
+  attn_set_force_tiled(on);
   return 0;
 }
 int fact_debug_gemm_nt_variant(int v) {

@@ -17,6 +17,7 @@ enum EpiKind : int {
   EPI_HEADS = 6,          // scatter to per-head token-major q/k/v style buffers [B*H][n_pad][dhp]
   EPI_ATOMIC_F32 = 7,     // atomicAdd(out0 f32, alpha * acc)   (split-K wgrad)
   EPI_F32_BF16 = 8,       // out0 f32 = acc, out1 bf16 = acc
+  EPI_F32_SLAB = 9,       // split-K partials: slab z at out0 + z*slab_stride, plain float4 stores
 };
 
 struct EpiParams {
@@ -35,6 +36,8 @@ struct EpiParams {
   bf16_t* hrow[3];  // [B*H][n_pad][dhp]
   int n_tok, n_pad, heads, dh, dhp, hid;
   float alpha;
+  size_t slab_stride;  // EPI_F32_SLAB: floats between consecutive k-split slabs
+  int z;               // (device) k-split index of this block, filled in by the kernel
 };
 
 struct GemmParams {

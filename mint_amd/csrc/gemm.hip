@@ -116,6 +116,15 @@ DEVINL void epilogue_store(const EpiParams& ep, int M, int N, int row, int col0,
           o1[r] = (bf16_t)v[r];
         }
     }
+  } else if constexpr (EPI == EPI_F32_SLAB) {
+    float* o = (float*)ep.out0 + (size_t)ep.z * ep.slab_stride + (size_t)row * ep.ldo0 + col0;
+    if (full && !(ep.ldo0 & 3)) {
+      *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col0 + r < N) o[r] = v[r];
+    }
   } else if constexpr (EPI == EPI_ATOMIC_F32) {
     float* o = (float*)ep.out0 + (size_t)row * ep.ldo0 + col0;
 #pragma unroll
@@ -132,7 +141,10 @@ constexpr bool kSwap = (EPI != EPI_ATOMIC_F32);
 // swapped:    acc[i][j] = rows m0+wm*64+i*16+(lane&15),       cols n0+wn*64+j*16+(lane>>4)*4 + r
 // un-swapped: acc[i][j] = rows m0+wm*64+i*16+(lane>>4)*4 + r,  cols n0+wn*64+j*16+(lane&15)
 template <int EPI>
-DEVINL void run_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane) {
+DEVINL void run_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane,
+                         int z = 0) {
+  EpiParams ep = p.ep;
+  ep.z = z;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -140,7 +152,7 @@ DEVINL void run_epilogue(const GemmParams& p, f32x4 (&acc)[4][4], int m0, int n0
       if constexpr (kSwap<EPI>) {
         const int row = m0 + wm * 64 + i * 16 + (lane & 15);
         const int col0 = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-        epilogue_store<EPI>(p.ep, p.M, p.N, row, col0, acc[i][j]);
+        epilogue_store<EPI>(ep, p.M, p.N, row, col0, acc[i][j]);
       } else {
         const int row0 = m0 + wm * 64 + i * 16 + (lane >> 4) * 4;
         const int col = n0 + wn * 64 + j * 16 + (lane & 15);
@@ -245,8 +257,11 @@ DEVINL void zero_acc(f32x4 (&acc)[4][4]) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+#ifndef GLDS_AUX
+#define GLDS_AUX 0
+#endif
 DEVINL void glds16(const bf16_t* src, unsigned char* lds_dst) {
-  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst, 16, 0, GLDS_AUX);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -303,7 +318,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast_kernel(const GemmParams p
     __syncthreads();
     buf ^= 1;
   }
-  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, bc.z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -483,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast_kernel(const GemmParams p
     __syncthreads();
     buf ^= 1;
   }
-  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, bc.z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -596,7 +611,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_tn_ring_kernel(const GemmPar
           acc[i][jj] = kSwap<EPI> ? mfma16(bfr[jj], af[i], acc[i][jj]) : mfma16(af[i], bfr[jj], acc[i][jj]);
     }
   }
-  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, z);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -670,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(const GemmParams p
     __syncthreads();
     buf ^= 1;
   }
-  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
+  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, bc.z);
 }
 
 int g_nt_variant = 0;  // 0 auto, 1 two-stage fast, 2 ring 128x128, 3 ring 256x128 (bench/test knob)
@@ -717,7 +732,7 @@ int check_common(const GemmParams& p, int epi) {
   if (p.M <= 0 || p.N <= 0 || p.K <= 0) return -1;
   if ((p.lda & 7) || (p.ldb & 7)) return -2;
   if (p.splitk < 1) return -3;
-  if (p.splitk > 1 && epi != EPI_ATOMIC_F32) return -4;
+  if (p.splitk > 1 && epi != EPI_ATOMIC_F32 && epi != EPI_F32_SLAB) return -4;
   if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return -5;
   if (epi == EPI_HEADS && ((p.ep.dh & 3) || (p.ep.dhp & 3))) return -8;
   return 0;
@@ -751,6 +766,7 @@ int launch_gemm_tn(int epi, const GemmParams& p, hipStream_t s) {
   switch (epi) {
     case EPI_BF16: return launch_tn_t<EPI_BF16>(p, s);
     case EPI_ATOMIC_F32: return launch_tn_t<EPI_ATOMIC_F32>(p, s);
+    case EPI_F32_SLAB: return launch_tn_t<EPI_F32_SLAB>(p, s);
   }
   return -7;
 }

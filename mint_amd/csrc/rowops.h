@@ -60,5 +60,7 @@ int launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
 // split the cross-modal gradient (B, na+nb, C) into the two encoder gradients (f32 + bf16 copies)
 int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, bf16_t* da16,
                       float* db, bf16_t* db16, hipStream_t s);
+// out[i] += sum_z slabs[z*stride + i], i < n (split-K partials -> gradient); stride % 4 == 0
+int launch_slab_reduce(const float* slabs, size_t stride, int nslab, float* out, size_t n, hipStream_t s);
 // sum of squares of a flat f32 buffer -> out[0] (atomicAdd), and flat scale
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s);

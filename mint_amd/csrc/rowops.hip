@@ -421,6 +421,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float4* __restrict__ g
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// out[i] += sum_z slabs[z*stride + i]  (split-K partial sums of a wgrad GEMM)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, size_t stride,
+                                                          int nslab, float* __restrict__ out, size_t n4) {
+  const size_t gs = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gs) {
+    float4 a = reinterpret_cast<float4*>(out)[i];
+    for (int z = 0; z < nslab; ++z) {
+      const float4 v = reinterpret_cast<const float4*>(slabs + (size_t)z * stride)[i];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = a;
+  }
+}
+__global__ void slab_reduce_tail_kernel(const float* __restrict__ slabs, size_t stride, int nslab,
+                                        float* __restrict__ out, size_t beg, size_t n) {
+  const size_t i = beg + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = out[i];
+  for (int z = 0; z < nslab; ++z) a += slabs[(size_t)z * stride + i];
+  out[i] = a;
+}
+
 inline int grid_for(size_t n, int block, int cap = 4096) {
   size_t g = (n + block - 1) / block;
   if (g > (size_t)cap) g = cap;
@@ -546,6 +568,14 @@ int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, 
   const size_t total = (size_t)B * (na + nb) * (C >> 2);
   hipLaunchKernelGGL(split_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)dx,
                      B, na, nb, C >> 2, (float4*)da, (bf16x4*)da16, (float4*)db, (bf16x4*)db16);
+  return 0;
+}
+
+int launch_slab_reduce(const float* slabs, size_t stride, int nslab, float* out, size_t n, hipStream_t s) {
+  if ((stride & 3) || ((uintptr_t)out & 15) || ((uintptr_t)slabs & 15)) return -1;
+  const size_t n4 = n >> 2;
+  if (n4) hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, s, slabs, stride, nslab, out, n4);
+  if (n & 3) hipLaunchKernelGGL(slab_reduce_tail_kernel, dim3(1), dim3(64), 0, s, slabs, stride, nslab, out, n4 << 2, n);
   return 0;
 }
 

@@ -160,7 +160,7 @@ def test_gemm_nt_epilogues():
 # ------------------------------------------------------------------------------------------------
 # GEMM TN (wgrad)
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("use_tr", [1, 0])
+@pytest.mark.parametrize("use_tr", [1, 0, 2], ids=["tr-atomic", "transpose", "tr-slab"])
 @pytest.mark.parametrize("K,Mo,No,splitk", [(128, 128, 128, 1), (512, 256, 384, 2), (5760, 800, 2400, 4),
                                             (1920, 800, 225, 3), (960, 225, 800, 2), (200, 72, 136, 1)])
 def test_gemm_tn(gemm_path, use_tr, K, Mo, No, splitk):
@@ -172,8 +172,11 @@ def test_gemm_tn(gemm_path, use_tr, K, Mo, No, splitk):
     A[:, :Mo] = _bf(torch.randn(K, Mo, device=DEV, generator=g))
     B[:, :No] = _bf(torch.randn(K, No, device=DEV, generator=g))
     out = torch.ones(Mo, No, device=DEV)
-    scratch = torch.empty(((Mo + 7) // 8 * 8 + (No + 7) // 8 * 8) * ((K + 7) // 8 * 8) + 64, device=DEV,
-                          dtype=torch.bfloat16)
+    if use_tr == 2:  # split-K slabs (fp32) + streaming reduce
+        scratch = torch.empty(splitk * ((Mo * No + 3) // 4 * 4), device=DEV, dtype=torch.float32)
+    else:
+        scratch = torch.empty(((Mo + 7) // 8 * 8 + (No + 7) // 8 * 8) * ((K + 7) // 8 * 8) + 64, device=DEV,
+                              dtype=torch.bfloat16)
     L.check(lib.fact_op_gemm_tn(L.ptr(A), lda, L.ptr(B), ldb, Mo, No, K, L.ptr(out), No, splitk, use_tr,
                                 L.ptr(scratch), L.cur_stream()))
     _sync()
@@ -248,9 +251,17 @@ def _attn_ref(qkv, B, H, n, dh, scale, dout=None):
     return out.detach(), x.grad
 
 
+@pytest.fixture(params=[0, 1], ids=["resident", "tiled"])
+def attn_path(request):
+    """LDS-resident kernels (when they fit) and the tiled streaming kernels."""
+    L.lib().fact_debug_attn_force_tiled(request.param)
+    yield request.param
+    L.lib().fact_debug_attn_force_tiled(0)
+
+
 @pytest.mark.parametrize("B,H,n,dh", [(2, 4, 32, 32), (1, 2, 96, 64), (2, 10, 360, 80), (2, 10, 120, 80),
-                                      (1, 10, 240, 80), (2, 3, 200, 128)])
-def test_attention_fwd_bwd(B, H, n, dh):
+                                      (1, 10, 240, 80), (2, 3, 200, 128), (3, 2, 376, 80), (1, 2, 400, 80)])
+def test_attention_fwd_bwd(attn_path, B, H, n, dh):
     lib = L.lib()
     hid = H * dh
     scale = hid ** -0.5  # the reference's quirk: full model dim, not head dim
@@ -274,7 +285,7 @@ def test_attention_fwd_bwd(B, H, n, dh):
         assert _rel_err(a, r) < 2e-2, "%s rel err %.4g" % (nm, _rel_err(a, r))
 
 
-def test_attention_peaked_softmax():
+def test_attention_peaked_softmax(attn_path):
     """Force the online-softmax rescale path: one key dominates late in the sequence."""
     lib = L.lib()
     B, H, n, dh = 1, 2, 160, 32

@@ -70,15 +70,15 @@ for (K, Mo, No) in TN_SHAPES:
     A = torch.randn(K, Mo, device=dev, generator=g).to(torch.bfloat16)
     B = torch.randn(K, No, device=dev, generator=g).to(torch.bfloat16)
     ref = A.float().t() @ B.float()
-    for tv in (0, 10):
-        lib.fact_debug_gemm_nt_variant(tv)
-        line = "K%5d Mo%5d No%5d tv%2d:" % (K, Mo, No, tv)
+    slab = torch.empty(6 * Mo * No, device=dev)
+    for tv in (1, 2):  # 1 = atomics, 2 = slabs + reduce
+        line = "K%5d Mo%5d No%5d mode%d:" % (K, Mo, No, tv)
         for splitk in (1, 2, 3, 4, 6):
             out = torch.zeros(Mo, No, device=dev)
 
             def launch():
-                L.check(lib.fact_op_gemm_tn(L.ptr(A), Mo, L.ptr(B), No, Mo, No, K, L.ptr(out), No, splitk, 1, None,
-                                            L.cur_stream()))
+                L.check(lib.fact_op_gemm_tn(L.ptr(A), Mo, L.ptr(B), No, Mo, No, K, L.ptr(out), No, splitk, tv,
+                                            L.ptr(slab), L.cur_stream()))
             launch()
             torch.cuda.synchronize()
             err = ((out - ref).norm() / ref.norm()).item()
