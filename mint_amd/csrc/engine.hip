@@ -471,10 +471,16 @@ AttnParams attn_params(const Stack& st, const LayerA& a, int B) {
 }
 
 // `to` waits for everything enqueued so far on `from` (no host sync). Returns the event used.
-hipEvent_t stream_after(FactHandle* h, hipStream_t from, hipStream_t to) {
+// NOTE: the caller's stream may legitimately be the null (legacy default) stream, so "no waiter" is
+// a separate entry point, never a null `to`.
+hipEvent_t stream_mark(FactHandle* h, hipStream_t from) {
   hipEvent_t e = h->ev[h->ev_i++ % h->ev.size()];
   (void)hipEventRecord(e, from);
-  if (to) (void)hipStreamWaitEvent(to, e, 0);
+  return e;
+}
+hipEvent_t stream_after(FactHandle* h, hipStream_t from, hipStream_t to) {
+  hipEvent_t e = stream_mark(h, from);
+  (void)hipStreamWaitEvent(to, e, 0);
   return e;
 }
 hipStream_t side_of(FactHandle* h, hipStream_t s) { return (h->use_side && h->side) ? h->side : s; }
@@ -522,7 +528,7 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx
   // ---- MLP block: x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
   if (two) stream_after(h, s, w);  // dx16 ready
   CHK(wgrad(h, a.g, ff, ff, dx16, d, d, M, G(h, p.w2.w), d, w));
-  hipEvent_t e_w2 = two ? stream_after(h, w, nullptr) : nullptr;
+  hipEvent_t e_w2 = two ? stream_mark(h, w) : nullptr;
   if (two && h->ev_dpre_free) (void)hipStreamWaitEvent(s, h->ev_dpre_free, 0);
   {
     GemmParams g = gp(dx16, d, p.w2.s, p.w2.lds, M, ff, d);
@@ -532,7 +538,7 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx
   if (two) stream_after(h, s, w);  // dpre ready
   CHK(wgrad(h, a.h2, d, d, h->dpre, ff, ff, M, G(h, p.w1.w), ff, w));
   CHK(launch_colsum_bf16(h->dpre, ff, G(h, p.b1), M, ff, ff, w));
-  if (two) h->ev_dpre_free = stream_after(h, w, nullptr);
+  if (two) h->ev_dpre_free = stream_mark(h, w);
   {
     GemmParams g = gp(h->dpre, ff, p.w1.s, p.w1.lds, M, d, ff);
     g.ep.out0 = h->dh; g.ep.ldo0 = d;
@@ -544,7 +550,7 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx
   // ---- attention block: x_mid = x_in + Wo attn(Wqkv LN1(x_in)) + bo
   if (two) stream_after(h, s, w);  // new dx16 ready
   CHK(wgrad(h, a.a, d, d, dx16, d, d, M, G(h, p.wo.w), d, w));
-  hipEvent_t e_wo = two ? stream_after(h, w, nullptr) : nullptr;
+  hipEvent_t e_wo = two ? stream_mark(h, w) : nullptr;
   {
     GemmParams g = gp(dx16, d, p.wo.s, p.wo.lds, M, d, d);
     bf16_t* row[1] = {h->dorow};
@@ -559,7 +565,7 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx
   }
   if (two) stream_after(h, s, w);  // dqkv ready
   CHK(wgrad(h, a.h1, d, d, h->dqkv, 3 * d, 3 * d, M, G(h, p.wqkv.w), 3 * d, w));
-  if (two) h->ev_dqkv_free = stream_after(h, w, nullptr);
+  if (two) h->ev_dqkv_free = stream_mark(h, w);
   {
     GemmParams g = gp(h->dqkv, 3 * d, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
     g.ep.out0 = h->dh; g.ep.ldo0 = d;
@@ -609,10 +615,7 @@ int model_forward_hidden(FactHandle* h, const float* motion, size_t m_stride, co
   for (int l = 0; l < mo.L; ++l) CHK(layer_forward(h, mo, l, B, s));
   if (w != s) stream_after(h, w, s);
   // tf.concat([motion, audio], axis=1)  (base_models.py:192-193)
-  const size_t rowb = (size_t)cr.d * sizeof(float);
-  CHK(copy2d(cr.x0, (size_t)cr.n * rowb, mo.out(), (size_t)mo.n * rowb, (size_t)mo.n * rowb, B, s));
-  CHK(copy2d(cr.x0 + (size_t)mo.n * cr.d, (size_t)cr.n * rowb, au.out(), (size_t)au.n * rowb,
-             (size_t)au.n * rowb, B, s));
+  CHK(launch_concat_seq(mo.out(), au.out(), B, mo.n, au.n, cr.d, cr.x0, s));
   for (int l = 0; l < cr.L; ++l) CHK(layer_forward(h, cr, l, B, s));
   return 0;
 }

@@ -57,6 +57,8 @@ int launch_pad_cast(const float* src, int n, size_t batch_stride, int M, int F, 
                     hipStream_t s);
 // f32 -> bf16 flat
 int launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
+// out (B, na+nb, C) = concat along the sequence axis of a (B, na, C) and b (B, nb, C)
+int launch_concat_seq(const float* a, const float* b, int B, int na, int nb, int C, float* out, hipStream_t s);
 // split the cross-modal gradient (B, na+nb, C) into the two encoder gradients (f32 + bf16 copies)
 int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, bf16_t* da16,
                       float* db, bf16_t* db16, hipStream_t s);

@@ -382,6 +382,20 @@ __global__ void cast_bf16_kernel(const float4* __restrict__ src, bf16x4* __restr
   }
 }
 
+// tf.concat([a, b], axis=1): out (B, na+nb, C) from a (B, na, C) and b (B, nb, C)
+__global__ void concat_seq_kernel(const float4* __restrict__ a, const float4* __restrict__ b, int B, int na,
+                                  int nb, int C4, float4* __restrict__ out) {
+  const size_t total = (size_t)B * (na + nb) * C4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t row = i / C4;
+    const int c = (int)(i - row * C4);
+    const int bi = (int)(row / (na + nb));
+    const int t = (int)(row - (size_t)bi * (na + nb));
+    out[i] = (t < na) ? a[((size_t)bi * na + t) * C4 + c] : b[((size_t)bi * nb + (t - na)) * C4 + c];
+  }
+}
+
 __global__ void split_grad_kernel(const float4* __restrict__ dx, int B, int na, int nb, int C4,
                                   float4* __restrict__ da, bf16x4* __restrict__ da16,
                                   float4* __restrict__ db, bf16x4* __restrict__ db16) {
@@ -559,6 +573,14 @@ int launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
   if (n & 3) return -1;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, s, (const float4*)src,
                      (bf16x4*)dst, n >> 2);
+  return 0;
+}
+
+int launch_concat_seq(const float* a, const float* b, int B, int na, int nb, int C, float* out, hipStream_t s) {
+  if (C & 3) return -1;
+  const size_t total = (size_t)B * (na + nb) * (C >> 2);
+  hipLaunchKernelGGL(concat_seq_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)a,
+                     (const float4*)b, B, na, nb, C >> 2, (float4*)out);
   return 0;
 }
 

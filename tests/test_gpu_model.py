@@ -259,3 +259,30 @@ def test_overlapped_allreduce_callback_path_single_rank():
         assert torch.allclose(results[0][1], results[1][1], rtol=1e-4, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+def test_scaled_config_dims_vs_oracle():
+    """BASELINE.json configs[4] dimensions (d=1536, 12 heads -> dh=128, ff=6144, seq 480/960, so the
+    cross stack runs n=1440 through the tiled attention kernels and LayerNorm at C=1536), with the
+    depth cut to 1+1+2 layers so the fp32 CPU oracle finishes in seconds."""
+    cfg = {"motion": {"seq_len": 480, "feature_dim": 225, "hidden": 1536, "layers": 1, "heads": 12, "ff": 6144},
+           "audio": {"seq_len": 960, "feature_dim": 35, "hidden": 1536, "layers": 1, "heads": 12, "ff": 6144},
+           "cross": {"hidden": 1536, "layers": 2, "heads": 12, "ff": 6144}, "out_dim": 225}
+    model = model_builder.build(make_config(cfg), True)
+    batch = O.synthetic_batch(cfg, 1, 20, seed=0, dtype=torch.float32)
+    gb = gpu_batch(batch)
+    model.build(1, 225, 35)
+    params = oracle_params(model, torch.float32)
+    out = model(gb)
+    ref_loss, ref_grads, ref = O.loss_and_grads(params, cfg, batch["motion_input"], batch["audio_input"],
+                                                batch["target"])
+    assert out.shape == (1, 1440, 225)
+    assert rel(out, ref) < 2e-2, rel(out, ref)
+    loss = model.forward_backward(gb, gb["target"])
+    assert abs(float(loss) - float(ref_loss)) / float(ref_loss) < 1e-2
+    grads = dict(zip(model.variable_names, model.gradients))
+    for name in ("cross_modal_layer/transformer/layer_0/attn/to_qkv/kernel",
+                 "cross_modal_layer/transformer/layer_1/mlp/dense_2/kernel",
+                 "motion_transformer/layer_0/mlp/dense_1/kernel", "audio_linear_embedding/kernel",
+                 "audio_transformer/layer_0/attn_norm/gamma"):
+        assert cos(grads[name], ref_grads[name]) > 0.98, name
