@@ -71,10 +71,15 @@ def gemm_roofline(device):
     ms = e0.elapsed_time(e1) / iters
     flops = 2.0 * M * N * K
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_nt_kernel<EPI_BIAS_GELU> M5760 N3072 K800",
+    traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/roofline_traffic.json)
+    try:
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))["traffic_bytes"]
+    except Exception:
+        pass
+    return {"bound": "mfma", "kernel": "gemm_nt_fast_kernel<EPI_BIAS_GELU> M5760 N3072 K800",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
-            "traffic": None}
+            "flop_per_launch": flops, "traffic": traffic}
 
 
 def usable_cores():
