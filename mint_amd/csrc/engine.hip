@@ -956,6 +956,7 @@ int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int
   g.ep.out0 = out0; g.ep.ldo0 = ldo0; g.ep.out1 = out1; g.ep.ldo1 = ldo1;
   g.ep.bias = bias; g.ep.pos = pos; g.ep.seq = seq; g.ep.resid = resid; g.ep.ldr = ldr;
   g.ep.pre = (const bf16_t*)pre; g.ep.ldp = ldp;
+  if (epi == EPI_ATOMIC_F32 && seq > 1) g.splitk = seq;  // bench hook: `seq` carries the K split
   CHK(launch_gemm_nt(epi, g, (hipStream_t)stream));
   return 0;
 }

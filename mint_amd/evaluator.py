@@ -1,0 +1,55 @@
+"""Evaluation loop: mirror of mint/ctl/single_task_evaluator.py (row f1).  One eval step runs the
+device-resident auto-regressive sampler for `steps` frames, prepends the seed motion and saves one
+`{motion_name}_{audio_name}.npy` of shape (seed + generated, 225) per sample — the file contract
+`tools/calculate_scores.py:210-215` consumes."""
+import os
+
+import numpy as np
+import torch
+
+
+class SingleTaskEvaluator:
+    def __init__(self, eval_dataset, model, metrics=None, output_dir=None, evaluator_options=None, steps=1200):
+        self.eval_dataset = eval_dataset
+        self.model = model
+        self.metrics = [] if metrics is None else (metrics if isinstance(metrics, list) else [metrics])
+        self.output_dir = output_dir
+        self.steps = steps
+
+    def eval_begin(self):
+        for metric in self.metrics:
+            metric.reset_states()
+
+    def eval_step(self, iterator):
+        inputs = next(iterator)
+        # [batch, steps, dim] -> [batch, seed + steps, dim]   (single_task_evaluator.py:69-71)
+        outputs = self.model.infer_auto_regressive(inputs, steps=self.steps)
+        seed = torch.as_tensor(inputs["motion_input"]).to(outputs.device, outputs.dtype)
+        outputs = torch.cat([seed, outputs], dim=1)
+        paths = []
+        if self.output_dir is not None:
+            os.makedirs(self.output_dir, exist_ok=True)
+            host = outputs.cpu().numpy()
+            for i in range(host.shape[0]):
+                path = os.path.join(self.output_dir, "%s_%s.npy" % (inputs["motion_name"][i], inputs["audio_name"][i]))
+                np.save(path, host[i])
+                paths.append(path)
+        for metric in self.metrics:
+            metric.update_state(inputs, outputs)
+        return outputs, paths
+
+    def eval_end(self):
+        return {metric.name: metric.result() for metric in self.metrics}
+
+    def evaluate(self, num_steps=-1):
+        """orbit.Controller.evaluate stand-in: one pass over the dataset."""
+        self.eval_begin()
+        it = iter(self.eval_dataset)
+        n = 0
+        while num_steps < 0 or n < num_steps:
+            try:
+                self.eval_step(it)
+            except StopIteration:
+                break
+            n += 1
+        return self.eval_end()

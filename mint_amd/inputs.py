@@ -1,0 +1,82 @@
+"""Batched input without tf.data: mirror of mint/core/inputs.py `create_input` (row f2).
+
+Yields dicts of torch tensors (`motion_input`, `audio_input`, `target`) plus the `motion_name` /
+`audio_name` string lists, batched with the GLOBAL train batch size per replica exactly like the
+reference (which drops the input_context, trainer.py:102-103).  CPU-side plumbing only; the
+benchmark uses synthetic tensors of the same shapes."""
+import glob as _glob
+import random
+
+import numpy as np
+import torch
+
+from mint_amd import inputs_util, tfrecord
+
+
+def _decode(payload, modalities):
+    ex = tfrecord.parse_example(payload)
+    out = {}
+    for m in modalities:
+        shape = tuple(int(x) for x in ex["%s_sequence_shape" % m])
+        out["%s_sequence" % m] = np.asarray(ex["%s_sequence" % m], dtype=np.float32).reshape(shape)
+        out["%s_name" % m] = ex["%s_name" % m][0].decode("utf-8")
+    return out
+
+
+def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_training=True, use_tpu=False,
+                 device=None, seed=None):
+    """Generator of feature dicts (inputs.py:20-123). Training: shuffle(100), repeat forever,
+    drop the remainder; eval: one pass in file order, remainder kept."""
+    batch_size = train_eval_config.batch_size
+    files = sorted(_glob.glob(dataset_config.data_files))
+    params = inputs_util.get_modality_to_param_dict(dataset_config)
+    use_fact = any(o.WhichOneof("preprocessor") == "fact_preprocessor"
+                   for o in dataset_config.data_augmentation_options)
+    rng = np.random.RandomState(seed)
+    pyrng = random.Random(seed)
+
+    def examples():
+        while True:
+            order = list(files)
+            if is_training:
+                pyrng.shuffle(order)
+            buf = []
+            for path in order:
+                for payload in tfrecord.read_records(path):
+                    ex = _decode(payload, list(params))
+                    if use_fact:
+                        ex = inputs_util.fact_preprocessing(ex, params, is_training, rng)
+                    if not is_training:
+                        yield ex
+                        continue
+                    buf.append(ex)
+                    if len(buf) >= 100:  # ds.shuffle(100)
+                        yield buf.pop(pyrng.randrange(len(buf)))
+            while buf:
+                yield buf.pop(pyrng.randrange(len(buf)))
+            if not is_training:
+                return
+
+    def collate(batch):
+        out = {}
+        for k in batch[0]:
+            if isinstance(batch[0][k], str):
+                out[k] = [b[k] for b in batch]
+            else:
+                t = torch.from_numpy(np.stack([b[k] for b in batch]))
+                if device is not None:
+                    t = t.pin_memory().to(device, non_blocking=True) if torch.cuda.is_available() else t
+                out[k] = t
+        return out
+
+    def batches():
+        batch = []
+        for ex in examples():
+            batch.append(ex)
+            if len(batch) == batch_size:
+                yield collate(batch)
+                batch = []
+        if batch and not is_training:
+            yield collate(batch)
+
+    return batches()
