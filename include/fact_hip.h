@@ -102,6 +102,16 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
  * counter and refreshes the bf16 weight shadows. */
 int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps, float clip_norm,
                    void* stream);
+/* Optimizer step fused INTO the backward pass (no gradient clipping): call fact_adam_begin before
+ * fact_forward_backward; every gradient bucket is then updated (Keras Adam + grad zeroing + bf16
+ * shadow refresh of that bucket) as soon as it is final - by the engine itself on an internal
+ * optimizer stream when no gradient callback is registered (the HBM-bound update hides behind the
+ * remaining MFMA/LDS-DMA-bound backward kernels and is joined before fact_forward_backward's work
+ * completes on the caller's stream), or by the host calling fact_adam_bucket(bucket, comm_stream)
+ * from its fact_grad_cb after that bucket's all-reduce.  Same arithmetic as fact_adam_step. */
+int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps);
+int fact_adam_bucket(FactHandle* h, int bucket, void* stream);
+int fact_num_buckets(FactHandle* h, int* n);
 int fact_get_step(FactHandle* h, int64_t* step);
 int fact_set_step(FactHandle* h, int64_t step);
 

@@ -52,6 +52,9 @@ SIGNATURES = {
     "fact_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "fact_forward_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "fact_adam_step": (_i, [_vp, _f, _f, _f, _f, _f, _vp]),
+    "fact_adam_begin": (_i, [_vp, _f, _f, _f, _f]),
+    "fact_adam_bucket": (_i, [_vp, _i, _vp]),
+    "fact_num_buckets": (_i, [_vp, C.POINTER(_i)]),
     "fact_get_step": (_i, [_vp, C.POINTER(C.c_int64)]),
     "fact_set_step": (_i, [_vp, C.c_int64]),
     "fact_infer_ar": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), _vp]),

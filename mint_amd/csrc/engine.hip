@@ -94,6 +94,14 @@ struct Bump {
   }
 };
 
+struct Bucket {
+  size_t off = 0, cnt = 0;  // float range in the arenas
+  int desc_first = 0, desc_n = 0, tiles = 0;
+};
+struct AdamArgs {
+  float lr_t = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, gscale = 1.f;
+};
+
 }  // namespace
 
 struct FactHandle {
@@ -127,8 +135,11 @@ struct FactHandle {
   float* dsum = nullptr;
   bf16_t *tA = nullptr, *tB = nullptr;  // transposed operands for the non-tr wgrad path
   float* ln_ws = nullptr;               // LayerNorm-backward per-block partial column sums
-  CastDesc* cast_table = nullptr;       // device table for the one-launch weight-shadow refresh
-  int cast_n = 0, cast_tiles = 0;
+  CastDesc* cast_table = nullptr;       // device tables for the per-bucket weight-shadow refresh
+  std::vector<Bucket> buckets;          // gradient / optimizer buckets in backward-completion order
+  AdamArgs adam;                        // hyper-parameters of the optimizer step in flight
+  bool adam_pending = false;            // fact_adam_begin called: buckets are updated inside backward
+  hipStream_t opt = nullptr;            // stream of the overlapped Adam + shadow refresh (HBM-bound)
   float* scalars = nullptr;             // [16] device scalars (loss, sumsq)
   bf16_t* ar_x16 = nullptr;             // AR: bf16 hidden rows of token 0 [B][d]
   float* ar_motion = nullptr;           // AR: extended motion track (B, n_m + steps, F_m)
@@ -362,11 +373,25 @@ void layout_work(FactHandle* h, Bump& b) {
 float* P(FactHandle* h, const Tensor& t) { return h->params + t.off; }
 float* G(FactHandle* h, const Tensor& t) { return h->grads + t.off; }
 
-// Build (once) the device table of every Dense kernel and refresh all bf16 shadows in ONE launch.
-int build_cast_table(FactHandle* h) {
+size_t tensor_end(const Tensor& t) { return rups(t.off + t.numel(), 64); }
+
+// Gradient / optimizer buckets: contiguous arena ranges in the order their gradients become final
+// during backward - head, cross layers L-1..0, audio stack, motion stack.  Each bucket carries the
+// device table of its Dense kernels so its bf16 shadows can be refreshed with one launch.
+int build_buckets(FactHandle* h) {
   std::vector<CastDesc> t;
-  int tiles = 0;
+  h->buckets.clear();
+  auto open = [&](size_t beg, size_t end) {
+    Bucket b;
+    b.off = beg;
+    b.cnt = end - beg;
+    b.desc_first = (int)t.size();
+    b.desc_n = 0;
+    b.tiles = 0;
+    h->buckets.push_back(b);
+  };
   auto add = [&](DenseW& w) {
+    Bucket& b = h->buckets.back();
     CastDesc d;
     d.src = P(h, w.w);
     d.s = w.s;
@@ -376,30 +401,52 @@ int build_cast_table(FactHandle* h) {
     d.lds = w.lds;
     d.ldt = w.ldt;
     d.tiles_x = (d.C + 63) / 64;
-    d.tile_begin = tiles;
-    tiles += d.tiles_x * ((d.R + 63) / 64);
+    d.tile_begin = b.tiles;
+    b.tiles += d.tiles_x * ((d.R + 63) / 64);
+    b.desc_n += 1;
     t.push_back(d);
   };
-  Stack* sts[3] = {&h->cross, &h->motion, &h->audio};
-  for (Stack* st : sts)
-    for (LayerP& p : st->lp) {
-      add(p.wqkv);
-      add(p.wo);
-      add(p.w1);
-      add(p.w2);
-    }
+  auto add_layer = [&](LayerP& p) {
+    add(p.wqkv);
+    add(p.wo);
+    add(p.w1);
+    add(p.w2);
+  };
+  Stack &cr = h->cross, &mo = h->motion, &au = h->audio;
+  open(h->head.w.off, tensor_end(h->head_b));
   add(h->head);
-  add(h->motion.emb);
-  add(h->audio.emb);
-  h->cast_n = (int)t.size();
-  h->cast_tiles = tiles;
+  for (int l = cr.L - 1; l >= 0; --l) {
+    open(cr.lp[l].ln1_g.off, tensor_end(cr.lp[l].b2));
+    add_layer(cr.lp[l]);
+  }
+  open(au.L ? au.lp[0].ln1_g.off : au.pos.off, tensor_end(au.emb_b));
+  for (LayerP& p : au.lp) add_layer(p);
+  add(au.emb);
+  open(mo.L ? mo.lp[0].ln1_g.off : mo.pos.off, tensor_end(mo.emb_b));
+  for (LayerP& p : mo.lp) add_layer(p);
+  add(mo.emb);
   HIPCHK(hipMalloc((void**)&h->cast_table, t.size() * sizeof(CastDesc)));
   HIPCHK(hipMemcpy(h->cast_table, t.data(), t.size() * sizeof(CastDesc), hipMemcpyHostToDevice));
   return 0;
 }
 
+int refresh_bucket(FactHandle* h, int b, hipStream_t s) {
+  const Bucket& k = h->buckets[b];
+  return launch_multi_cast_transpose(h->cast_table + k.desc_first, k.desc_n, k.tiles, s);
+}
+
 int refresh_all(FactHandle* h, hipStream_t s) {
-  return launch_multi_cast_transpose(h->cast_table, h->cast_n, h->cast_tiles, s);
+  for (int b = 0; b < (int)h->buckets.size(); ++b) CHK(refresh_bucket(h, b, s));
+  return 0;
+}
+
+// Keras-Adam on one bucket (params, m, v updated; grads zeroed) + its shadow refresh
+int adam_bucket(FactHandle* h, int b, hipStream_t s) {
+  const Bucket& k = h->buckets[b];
+  const AdamArgs& a = h->adam;
+  CHK(launch_adam(h->params + k.off, h->adam_m + k.off, h->adam_v + k.off, h->grads + k.off, k.cnt, a.lr_t,
+                  a.b1, a.b2, a.eps, a.gscale, s));
+  return refresh_bucket(h, b, s);
 }
 
 int g_force_generic_gemm = 0;  // test knob (fact_debug_force_generic_gemm)
@@ -620,16 +667,25 @@ int model_forward_hidden(FactHandle* h, const float* motion, size_t m_stride, co
   return 0;
 }
 
-size_t tensor_end(const Tensor& t) { return rups(t.off + t.numel(), 64); }
-
-// Every kernel that contributes to grads[beg, end) has been enqueued (main + side stream): make the
+// Every kernel that contributes to the next bucket's gradients has been enqueued (main + side): make the
 // caller's communication stream wait for them and tell the host, which enqueues the all-reduce of
-// that range there.  Nothing blocks; the collective overlaps the rest of the backward pass.
-void notify_grads(FactHandle* h, size_t beg, size_t end, hipStream_t s) {
-  if (!h->cb) return;
-  stream_after(h, s, h->cb_stream);
-  if (side_of(h, s) != s) stream_after(h, h->side, h->cb_stream);
-  h->cb(h->cb_user, h->cb_bucket++, beg, end - beg);
+// that range there (and, with a fused optimizer step, the bucket's Adam right behind it).  Without
+// a callback and with fact_adam_begin pending, the bucket's Adam + shadow refresh is enqueued here
+// on the optimizer stream: it is HBM-bound while the remaining backward GEMMs are LDS-DMA/MFMA-bound,
+// so it hides behind them.  Nothing blocks the host.
+int notify_grads(FactHandle* h, hipStream_t s) {
+  const int b = h->cb_bucket++;
+  const Bucket& k = h->buckets[b];
+  if (h->cb) {
+    stream_after(h, s, h->cb_stream);
+    if (side_of(h, s) != s) stream_after(h, h->side, h->cb_stream);
+    h->cb(h->cb_user, b, k.off, k.cnt);
+  } else if (h->adam_pending) {
+    stream_after(h, s, h->opt);
+    if (side_of(h, s) != s) stream_after(h, h->side, h->opt);
+    CHK(adam_bucket(h, b, h->opt));
+  }
+  return 0;
 }
 
 int check_batch(FactHandle* h, int B) {
@@ -725,10 +781,11 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
     layout_work(h, b2);
   }
   {
-    int rc2 = build_cast_table(h);
+    int rc2 = build_buckets(h);
     if (rc2) return rc2;
   }
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&h->opt, hipStreamNonBlocking));
   h->ev.resize(64);
   for (hipEvent_t& e : h->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *out = h;
@@ -748,6 +805,7 @@ int fact_destroy(FactHandle* h) {
   (void)hipFree(h->cast_table);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->opt) (void)hipStreamDestroy(h->opt);
   (void)hipFree(h->ar_motion);
   delete h;
   return 0;
@@ -853,19 +911,23 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   // Gradient buckets are contiguous arena ranges reported in the order they become final:
   // head, cross layers L-1..0, audio stack, motion stack (fact_set_grad_callback).
   h->cb_bucket = 0;
-  notify_grads(h, h->head.w.off, tensor_end(h->head_b), s);
+  CHK(notify_grads(h, s));  // head
   for (int l = cr.L - 1; l >= 0; --l) {
     CHK(layer_backward(h, cr, l, B, h->dx, h->dx16, s));
-    notify_grads(h, cr.lp[l].ln1_g.off, tensor_end(cr.lp[l].b2), s);
+    CHK(notify_grads(h, s));  // cross layer l
   }
   CHK(launch_split_grad(h->dx, B, mo.n, au.n, d, h->dxm, h->dxm16, h->dxa, h->dxa16, s));
   for (int l = au.L - 1; l >= 0; --l) CHK(layer_backward(h, au, l, B, h->dxa, h->dxa16, s));
   CHK(embed_backward(h, au, B, h->dxa, h->dxa16, s));
-  notify_grads(h, au.L ? au.lp[0].ln1_g.off : au.pos.off, tensor_end(au.emb_b), s);
+  CHK(notify_grads(h, s));  // audio stack
   for (int l = mo.L - 1; l >= 0; --l) CHK(layer_backward(h, mo, l, B, h->dxm, h->dxm16, s));
   CHK(embed_backward(h, mo, B, h->dxm, h->dxm16, s));
-  notify_grads(h, mo.L ? mo.lp[0].ln1_g.off : mo.pos.off, tensor_end(mo.emb_b), s);
+  CHK(notify_grads(h, s));  // motion stack
   if (side_of(h, s) != s) stream_after(h, h->side, s);  // join: the caller's stream sees all gradients
+  if (h->adam_pending && !h->cb) {  // fused optimizer step: join the optimizer stream, step is complete
+    stream_after(h, h->opt, s);
+    h->adam_pending = false;
+  }
   h->ev_dpre_free = nullptr;
   h->ev_dqkv_free = nullptr;
   return 0;
@@ -893,6 +955,35 @@ int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps,
   CHK(launch_adam(h->params, h->adam_m, h->adam_v, h->grads, h->arena_floats, (float)lr_t, beta1, beta2,
                   eps, gscale, s));
   return refresh_all(h, s);
+}
+
+int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps) {
+  if (!h) return fail(-1, "null handle");
+  if (!h->training) return fail(-1, "handle was created with training=0");
+  h->step += 1;
+  const double t = (double)h->step;
+  h->adam.lr_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t)));
+  h->adam.b1 = beta1;
+  h->adam.b2 = beta2;
+  h->adam.eps = eps;
+  h->adam.gscale = 1.0f;
+  h->adam_pending = true;
+  return 0;
+}
+
+int fact_adam_bucket(FactHandle* h, int bucket, void* stream) {
+  if (!h) return fail(-1, "null handle");
+  if (!h->adam_pending) return fail(-1, "fact_adam_bucket without fact_adam_begin");
+  if (bucket < 0 || bucket >= (int)h->buckets.size()) return fail(-1, "bucket index out of range");
+  CHK(adam_bucket(h, bucket, (hipStream_t)stream));
+  if (bucket == (int)h->buckets.size() - 1) h->adam_pending = false;
+  return 0;
+}
+
+int fact_num_buckets(FactHandle* h, int* n) {
+  if (!h || !n) return fail(-1, "null argument");
+  *n = (int)h->buckets.size();
+  return 0;
 }
 
 int fact_get_step(FactHandle* h, int64_t* step) {

@@ -246,6 +246,20 @@ class FACTModel:
                                               float(loss_scale), L.ptr(self._loss_buf), L.cur_stream()))
         return self._loss_buf[0]
 
+    def ensure_built(self, inputs):
+        """Create the engine for this batch if it does not exist yet (Keras builds on first call)."""
+        self._inputs(inputs)
+
+    def begin_fused_adam(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        """The next forward_backward also applies the optimizer step, bucket by bucket, overlapped
+        with the rest of the backward pass (see include/fact_hip.h fact_adam_begin)."""
+        self._require_built()
+        L.check(L.lib().fact_adam_begin(self._h, float(lr), float(beta_1), float(beta_2), float(epsilon)))
+        self.global_step += 1
+
+    def adam_bucket(self, bucket, stream):
+        L.check(L.lib().fact_adam_bucket(self._h, int(bucket), C.c_void_p(stream.cuda_stream)))
+
     def apply_adam(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clip_norm=0.0):
         L.check(L.lib().fact_adam_step(self._h, float(lr), float(beta_1), float(beta_2), float(epsilon),
                                        float(clip_norm), L.cur_stream()))

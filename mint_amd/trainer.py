@@ -51,6 +51,13 @@ class Adam:
         self.iterations += 1
         return lr
 
+    def begin_fused(self, model):
+        """Arm the optimizer step that the engine applies inside the coming backward pass."""
+        lr = self.learning_rate(self.iterations)
+        model.begin_fused_adam(lr, self.beta_1, self.beta_2, self.epsilon)
+        self.iterations += 1
+        return lr
+
 
 def replica_count():
     if dist is not None and dist.is_available() and dist.is_initialized():
@@ -85,12 +92,18 @@ class OverlappedGradReducer:
         self.model = model
         self.comm = torch.cuda.Stream()
         self.works = []
+        self.fused_adam = False  # set per step by the trainer
         model.set_grad_callback(self._on_bucket, self.comm)
 
     def _on_bucket(self, bucket, offset, count):
         with torch.cuda.stream(self.comm):
-            self.works.append(dist.all_reduce(self.model.grad_arena[offset:offset + count],
-                                              op=dist.ReduceOp.SUM, async_op=True))
+            w = dist.all_reduce(self.model.grad_arena[offset:offset + count], op=dist.ReduceOp.SUM,
+                                async_op=True)
+            if self.fused_adam:
+                w.wait()  # comm stream waits for the collective, then updates this bucket
+                self.model.adam_bucket(bucket, self.comm)
+            else:
+                self.works.append(w)
 
     def finish(self):
         for w in self.works:
@@ -107,7 +120,8 @@ class SingleTaskTrainer:
     reference's loss, fact_model.py:143-148, fused with the backward pass)."""
 
     def __init__(self, train_dataset, label_key, model, loss_fn=None, optimizer=None, metrics=None,
-                 trainer_options=None, summary_fn=None, grad_clip_norm=0.0, overlap_grad_allreduce=None):
+                 trainer_options=None, summary_fn=None, grad_clip_norm=0.0, overlap_grad_allreduce=None,
+                 fuse_optimizer=True):
         self.train_dataset = train_dataset
         self.label_key = label_key
         self.model = model
@@ -132,6 +146,8 @@ class SingleTaskTrainer:
             overlap_grad_allreduce = (self.num_replicas_in_sync > 1 and hasattr(model, "set_grad_callback")
                                       and dist.get_backend() == "nccl")
         self._overlap = bool(overlap_grad_allreduce)  # reducer is created lazily (model builds on 1st batch)
+        # optimizer step inside backward: needs the engine API and no global-norm clipping
+        self._fuse = bool(fuse_optimizer) and hasattr(model, "begin_fused_adam") and not (grad_clip_norm > 0.)
 
     def train_loop_begin(self):
         self.train_loss.reset_states()
@@ -150,8 +166,19 @@ class SingleTaskTrainer:
         inputs = dict(next(iterator))
         target = inputs.pop(self.label_key)  # the model never sees it
         R = self.num_replicas_in_sync
-        if self._overlap and self._reducer is None and getattr(self.model, "_h", None) is not None:
+        if (self._overlap or self._fuse) and hasattr(self.model, "ensure_built"):
+            self.model.ensure_built(inputs)
+        if self._overlap and self._reducer is None:
             self._reducer = OverlappedGradReducer(self.model)
+        # fused path: single replica (engine updates buckets itself) or overlapped DP (reducer does)
+        fused = self._fuse and (R == 1 or self._reducer is not None)
+        lr = None
+        if fused:
+            lr = self.optimizer.begin_fused(self.model)
+            if self._reducer is not None:
+                self._reducer.fused_adam = True
+        elif self._reducer is not None:
+            self._reducer.fused_adam = False
         raw_loss = self.model.forward_backward(inputs, target, loss_scale=1.0 / R)
         loss = raw_loss / R
         regularization_loss = 0.0  # model.losses is empty: no regularisers
@@ -161,11 +188,10 @@ class SingleTaskTrainer:
                             self.optimizer.iterations)
         if self._reducer is not None:
             self._reducer.finish()
-        else:
+        elif not fused:
             allreduce_gradients(self.model.grad_arena)
-            if self._overlap:  # first step: the engine was only built inside forward_backward
-                self._reducer = OverlappedGradReducer(self.model)
-        lr = self.optimizer.apply_gradients(self.model, clip_norm=self.grad_clip_norm)
+        if not fused:
+            lr = self.optimizer.apply_gradients(self.model, clip_norm=self.grad_clip_norm)
         self.train_loss.update_state(total_loss)
         self.task_loss.update_state(loss)
         self.regularization_loss.update_state(regularization_loss)

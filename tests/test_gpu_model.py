@@ -241,6 +241,7 @@ def test_overlapped_allreduce_callback_path_single_rank():
             if overlap:
                 assert tr._reducer is not None
                 orig = tr._reducer._on_bucket
+                tr._reducer.fused_adam = False  # plain forward_backward below: no optimizer step armed
                 tr._reducer.model.set_grad_callback(lambda b, o, c: (seen.append((b, o, c)), orig(b, o, c)),
                                                     tr._reducer.comm)
                 batch2 = dict(batch)
@@ -321,3 +322,22 @@ def test_checkpoint_resume_and_evaluator_on_engine(tmp_path):
     a = np.load(tmp_path / "eval" / "gA_m0.npy")
     assert a.shape == (32 + 3, 225)  # 3 full audio windows available
     np.testing.assert_allclose(a[:32], batch["motion_input"][0].cpu().numpy())
+
+
+def test_fused_optimizer_in_backward_matches_separate_step():
+    """fact_adam_begin + per-bucket Adam on the optimizer stream inside backward == forward_backward
+    followed by fact_adam_step (same kernels, same arithmetic, different scheduling)."""
+    cfg = O.TINY_CFG
+    batches = [gpu_batch(O.synthetic_batch(cfg, 4, 8, seed=s)) for s in (1, 2, 3, 4)]
+    finals = []
+    for fuse in (False, True):
+        model = model_builder.build(make_config(cfg), True)
+        tr = SingleTaskTrainer(batches, "target", model, optimizer=Adam(1e-3), fuse_optimizer=fuse)
+        it = iter(batches)
+        losses = [float(tr.train_step(it)) for _ in range(4)]
+        torch.cuda.synchronize()
+        assert tr.optimizer.iterations == 4 and model.global_step == 4
+        assert float(model.grad_arena.abs().max()) == 0.0  # every bucket consumed and zeroed
+        finals.append((losses, torch.cat([v.flatten() for v in model.trainable_variables]).cpu()))
+    assert finals[0][0] == pytest.approx(finals[1][0], rel=1e-6)
+    assert torch.allclose(finals[0][1], finals[1][1], rtol=1e-5, atol=1e-7)
