@@ -373,8 +373,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
       f32x4 p0, p1, d0, d1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p0[r] = kvalid[ks] ? __builtin_amdgcn_exp2f(s[0][ks][r] * sc - l2a[r]) : 0.f;
-        p1[r] = kvalid[ks] ? __builtin_amdgcn_exp2f(s[1][ks][r] * sc - l2b[r]) : 0.f;
+        // padded keys AND padded query rows are masked: the dO scratch is shared by stacks of different
+        // geometry, so its padding rows are not guaranteed to be zero
+        const bool qv0 = (qt * 32 + g * 4 + r) < p.n, qv1 = (qt * 32 + 16 + g * 4 + r) < p.n;
+        p0[r] = (kvalid[ks] && qv0) ? __builtin_amdgcn_exp2f(s[0][ks][r] * sc - l2a[r]) : 0.f;
+        p1[r] = (kvalid[ks] && qv1) ? __builtin_amdgcn_exp2f(s[1][ks][r] * sc - l2b[r]) : 0.f;
         d0[r] = p0[r] * (dp[0][ks][r] - dda[r]);
         d1[r] = p1[r] * (dp[1][ks][r] - ddb[r]);
       }
@@ -773,8 +776,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_res_kernel(const AttnParams
         f32x4 p0, p1, d0, d1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          p0[r] = kvalid[ks] ? __builtin_amdgcn_exp2f(fmaf(s[0][ks][r], sc, -l2a[r])) : 0.f;
-          p1[r] = kvalid[ks] ? __builtin_amdgcn_exp2f(fmaf(s[1][ks][r], sc, -l2b[r])) : 0.f;
+          // padded keys AND padded query rows are masked (shared dO scratch: see the tiled kernel)
+          const bool qv0 = (qt * 32 + g * 4 + r) < p.n, qv1 = (qt * 32 + 16 + g * 4 + r) < p.n;
+          p0[r] = (kvalid[ks] && qv0) ? __builtin_amdgcn_exp2f(fmaf(s[0][ks][r], sc, -l2a[r])) : 0.f;
+          p1[r] = (kvalid[ks] && qv1) ? __builtin_amdgcn_exp2f(fmaf(s[1][ks][r], sc, -l2b[r])) : 0.f;
           d0[r] = p0[r] * (dp[0][ks][r] - dda[r]);
           d1[r] = p1[r] * (dp[1][ks][r] - ddb[r]);
         }

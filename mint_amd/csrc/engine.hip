@@ -786,7 +786,7 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
   }
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->opt, hipStreamNonBlocking));
-  h->ev.resize(64);
+  h->ev.resize(1024);  // ~170 records per train step: a stored handle is never re-recorded before its use
   for (hipEvent_t& e : h->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *out = h;
   return 0;

@@ -341,3 +341,29 @@ def test_fused_optimizer_in_backward_matches_separate_step():
         finals.append((losses, torch.cat([v.flatten() for v in model.trainable_variables]).cpu()))
     assert finals[0][0] == pytest.approx(finals[1][0], rel=1e-6)
     assert torch.allclose(finals[0][1], finals[1][1], rtol=1e-5, atol=1e-7)
+
+
+def test_ragged_lengths_second_step_grads():
+    """Sequence lengths that are not multiples of the 32-token attention tile (40 / 72 / 112) and a
+    SECOND backward pass through the shared scratch buffers: padding rows of the per-head dO scratch
+    hold leftovers of the previous stack / step and must not leak into dK/dV."""
+    cfg = {"motion": {"seq_len": 40, "feature_dim": 225, "hidden": 128, "layers": 2, "heads": 4, "ff": 256},
+           "audio": {"seq_len": 72, "feature_dim": 35, "hidden": 128, "layers": 2, "heads": 4, "ff": 256},
+           "cross": {"hidden": 128, "layers": 2, "heads": 4, "ff": 256}, "out_dim": 225}
+    model = model_builder.build(make_config(cfg), True)
+    b1 = O.synthetic_batch(cfg, 3, 10, seed=1)
+    b2 = O.synthetic_batch(cfg, 3, 10, seed=2)
+    model.build(3, 225, 35)
+    _randomize(model)
+    params = oracle_params(model)
+    g1 = gpu_batch(b1)
+    model.forward_backward(g1, g1["target"])   # dirty every scratch buffer
+    model.grad_arena.zero_()
+    g2 = gpu_batch(b2)
+    loss = model.forward_backward(g2, g2["target"])
+    ref_loss, ref_grads, _ = O.loss_and_grads(params, cfg, b2["motion_input"], b2["audio_input"], b2["target"])
+    assert abs(float(loss) - float(ref_loss)) / float(ref_loss) < 1e-2
+    for name, g in zip(model.variable_names, model.gradients):
+        r = ref_grads[name]
+        if float(r.norm()) > 1e-12:
+            assert cos(g, r) > 0.995, "%s cos %.5f" % (name, cos(g, r))
