@@ -63,6 +63,8 @@ SIGNATURES = {
     "fact_op_gemm_nt": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i,
                              _vp, _i, _vp]),
     "fact_op_gemm_tn": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "fact_op_gemm_tn_grouped": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
+                                     C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), _i, _i, _vp, _sz, C.POINTER(_sz), _vp]),
     "fact_op_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "fact_op_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fact_op_attention_scratch": (_sz, [_i, _i, _i, _i]),
@@ -73,6 +75,8 @@ SIGNATURES = {
     "fact_probe_tr": (_i, [_vp, _i, _vp, _vp, _vp]),
     "fact_debug_force_generic_gemm": (_i, [_i]),
     "fact_debug_gemm_nt_variant": (_i, [_i]),
+    "fact_debug_gemm_nt_band": (_i, [_i]),
+    "fact_debug_ln_bwd": (_i, [_i, _i]),
     "fact_debug_attn_force_tiled": (_i, [_i]),
 }
 

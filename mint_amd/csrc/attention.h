@@ -25,6 +25,7 @@ struct AttnParams {
   float* dsum;        // [B*H][NP] rowsum(dO * O)
   bf16_t* dqkv;       // bwd output [B*n][3*hid] in (qkv h d) column order
   int B, H, n, NP, hid, dh;
+  int ldo, ldq;       // row pitches (elements) of out/o and of dqkv (>= hid, >= 3*hid)
   float scale;
 };
 

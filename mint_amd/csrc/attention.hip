@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const int t = q0 + qs * 16 + (lane & 15);
     if (g == 0 && t < p.NP) p.lse2[(size_t)bh * p.NP + t] = m[qs] + __log2f(lt);
     if (t < p.n) {
-      bf16_t* orow = p.out + ((size_t)b * p.n + t) * p.hid + h * DH + g * 4;
+      bf16_t* orow = p.out + ((size_t)b * p.n + t) * p.ldo + h * DH + g * 4;
 #pragma unroll
       for (int dt = 0; dt < G::ND; ++dt) {
         bf16x4 o = {(bf16_t)(O[qs][dt][0] * inv), (bf16_t)(O[qs][dt][1] * inv),
@@ -186,7 +186,7 @@ __global__ void attn_bwd_prep_kernel(const AttnParams p) {
   if (t < p.n) {
     const int b = bh / p.H, h = bh - b * p.H;
     const bf16_t* d = p.dorow + ((size_t)bh * p.NP + t) * G::DHP;
-    const bf16_t* o = p.o + ((size_t)b * p.n + t) * p.hid + h * DH;
+    const bf16_t* o = p.o + ((size_t)b * p.n + t) * p.ldo + h * DH;
 #pragma unroll
     for (int c = 0; c < DH; c += 8) {
       const bf16x8 dv = *reinterpret_cast<const bf16x8*>(d + c);
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnParams p) {
   for (int qs = 0; qs < 2; ++qs) {
     const int t = q0 + qs * 16 + (lane & 15);
     if (t < p.n) {
-      bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * (3 * p.hid) + h * DH + g * 4;
+      bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * p.ldq + h * DH + g * 4;
 #pragma unroll
       for (int dt = 0; dt < G::ND; ++dt) {
         bf16x4 o = {(bf16_t)(dQ[qs][dt][0] * p.scale), (bf16_t)(dQ[qs][dt][1] * p.scale),
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const AttnParams p) 
   for (int ks = 0; ks < 2; ++ks) {
     const int t = key0 + ks * 16 + (lane & 15);
     if (t < p.n) {
-      bf16_t* krow_o = p.dqkv + ((size_t)b * p.n + t) * (3 * p.hid) + p.hid + h * DH + g * 4;
+      bf16_t* krow_o = p.dqkv + ((size_t)b * p.n + t) * p.ldq + p.hid + h * DH + g * 4;
       bf16_t* vrow_o = krow_o + p.hid;
 #pragma unroll
       for (int dt = 0; dt < G::ND; ++dt) {
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(768) void attn_fwd_res_kernel(const AttnParams p) {
     const int t = q0 + qs * 16 + (lane & 15);
     if (g == 0 && t < p.NP) p.lse2[(size_t)bh * p.NP + t] = m[qs] + __log2f(lt);
     if (t < p.n) {
-      bf16_t* orow = p.out + ((size_t)b * p.n + t) * p.hid + h * DH + g * 4;
+      bf16_t* orow = p.out + ((size_t)b * p.n + t) * p.ldo + h * DH + g * 4;
 #pragma unroll
       for (int dt = 0; dt < G::ND; ++dt) {
         bf16x4 o = {(bf16_t)(O[qs][dt][0] * inv), (bf16_t)(O[qs][dt][1] * inv),
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_res_kernel(const AttnParams p
   for (int qs = 0; qs < 2; ++qs) {
     const int t = q0 + qs * 16 + (lane & 15);
     if (t < p.n) {
-      bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * (3 * p.hid) + h * DH + g * 4;
+      bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * p.ldq + h * DH + g * 4;
 #pragma unroll
       for (int dt = 0; dt < G::ND; ++dt) {
         bf16x4 o = {(bf16_t)(dQ[qs][dt][0] * p.scale), (bf16_t)(dQ[qs][dt][1] * p.scale),
@@ -801,7 +801,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_res_kernel(const AttnParams
     for (int ks = 0; ks < 2; ++ks) {
       const int t = key0 + ks * 16 + (lane & 15);
       if (t < p.n) {
-        bf16_t* krow_o = p.dqkv + ((size_t)b * p.n + t) * (3 * p.hid) + p.hid + h * DH + g * 4;
+        bf16_t* krow_o = p.dqkv + ((size_t)b * p.n + t) * p.ldq + p.hid + h * DH + g * 4;
         bf16_t* vrow_o = krow_o + p.hid;
 #pragma unroll
         for (int dt = 0; dt < G::ND; ++dt) {
@@ -838,6 +838,7 @@ int check(const AttnParams& p) {
   if (p.NP % 128 != 0 || p.NP < p.n) return -2;
   if (p.hid != p.H * p.dh) return -3;
   if (p.hid % 4 != 0) return -4;
+  if (p.ldo < p.hid || (p.ldo & 3) || (p.dqkv && (p.ldq < 3 * p.hid || (p.ldq & 3)))) return -6;
   return 0;
 }
 

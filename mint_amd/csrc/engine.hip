@@ -24,6 +24,11 @@
 
 namespace {
 
+// bf16 row pitches are multiples of 64 elements (128 B): a 64-deep K-step chunk of a row is then
+// exactly one cache line (an 800-wide row at pitch 800 straddles two lines on every odd row, which
+// costs ~10 % of the K = 800 GEMMs - tools/gemm_bench.py).
+constexpr int kPitch = 64;
+
 thread_local std::string g_err;
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -72,6 +77,7 @@ struct LayerA {
 struct Stack {
   const char* name = "";
   int n = 0, feat = 0, featp = 0, d = 0, H = 0, dh = 0, dhp = 0, ff = 0, L = 0, NP = 0;
+  int dp = 0, qp = 0, fp = 0;  // bf16 row pitches of [.][d], [.][3d], [.][ff] activations (multiples of 64)
   std::vector<LayerP> lp;
   std::vector<LayerA> la;
   // embedding (modal stacks only)
@@ -238,6 +244,9 @@ void init_stack_geo(Stack& st, const char* name, const FactStackCfg& c, int n, i
   st.dh = c.heads > 0 ? c.hidden / c.heads : 0;
   st.dhp = rup(st.dh, 32);
   st.ff = c.ff;
+  st.dp = rup(st.d, kPitch);
+  st.qp = rup(3 * st.d, kPitch);
+  st.fp = rup(st.ff, kPitch);
   st.L = c.layers;
   st.NP = rup(n, 128);
 }
@@ -268,8 +277,8 @@ int validate(const FactConfig& c) {
 }
 
 void layout_dense(Bump& b, DenseW& w) {
-  w.lds = rup(w.w.cols, 32);
-  w.ldt = rup(w.w.rows, 32);
+  w.lds = rup(w.w.cols, kPitch);
+  w.ldt = rup(w.w.rows, kPitch);
   w.s = b.take<bf16_t>((size_t)w.w.rows * w.lds);
   w.t = b.take<bf16_t>((size_t)w.w.cols * w.ldt);
 }
@@ -304,11 +313,11 @@ void layout_stack_acts(FactHandle* h, Bump& b, Stack& st, int B) {
     a.rstd1 = b.take<float>(M);
     a.mean2 = b.take<float>(M);
     a.rstd2 = b.take<float>(M);
-    a.h1 = b.take<bf16_t>(M * st.d);
-    a.a = b.take<bf16_t>(M * st.d);
-    a.h2 = b.take<bf16_t>(M * st.d);
-    a.pre = b.take<bf16_t>(M * st.ff);
-    a.g = b.take<bf16_t>(M * st.ff);
+    a.h1 = b.take<bf16_t>(M * st.dp);
+    a.a = b.take<bf16_t>(M * st.dp);
+    a.h2 = b.take<bf16_t>(M * st.dp);
+    a.pre = b.take<bf16_t>(M * st.fp);
+    a.g = b.take<bf16_t>(M * st.fp);
     for (int w = 0; w < 3; ++w) {
       a.row[w] = b.take<bf16_t>(BH * st.NP * st.dhp);
     }
@@ -332,17 +341,17 @@ void layout_work(FactHandle* h, Bump& b) {
   layout_stack_acts(h, b, h->motion, B);
   layout_stack_acts(h, b, h->audio, B);
   layout_stack_acts(h, b, h->cross, B);
-  const int d = h->cross.d;
+  const int d = h->cross.d, dp = h->cross.dp;
   const size_t Mc = (size_t)B * h->cross.n;
   const size_t Mm = (size_t)B * h->motion.n, Ma = (size_t)B * h->audio.n;
-  h->xf16 = b.take<bf16_t>(Mc * d);
+  h->xf16 = b.take<bf16_t>(Mc * dp);
   h->pred = b.take<float>(Mc * h->cfg.out_dim);
   h->scalars = b.take<float>(16);
   h->ar_x16 = b.take<bf16_t>((size_t)B * d);
   if (h->training) {
-    int ffmax = h->cross.ff;
-    if (h->motion.ff > ffmax) ffmax = h->motion.ff;
-    if (h->audio.ff > ffmax) ffmax = h->audio.ff;
+    int ffmax = h->cross.fp;
+    if (h->motion.fp > ffmax) ffmax = h->motion.fp;
+    if (h->audio.fp > ffmax) ffmax = h->audio.fp;
     size_t rowmax = 0, lsemax = 0;
     Stack* sts[3] = {&h->cross, &h->motion, &h->audio};
     for (Stack* st : sts) {
@@ -352,14 +361,14 @@ void layout_work(FactHandle* h, Bump& b) {
     }
     h->dpred = b.take<bf16_t>(Mc * h->outp);
     h->dx = b.take<float>(Mc * d);
-    h->dx16 = b.take<bf16_t>(Mc * d);
+    h->dx16 = b.take<bf16_t>(Mc * dp);
     h->dxm = b.take<float>(Mm * d);
-    h->dxm16 = b.take<bf16_t>(Mm * d);
+    h->dxm16 = b.take<bf16_t>(Mm * dp);
     h->dxa = b.take<float>(Ma * d);
-    h->dxa16 = b.take<bf16_t>(Ma * d);
-    h->dh = b.take<bf16_t>(Mc * d);
+    h->dxa16 = b.take<bf16_t>(Ma * dp);
+    h->dh = b.take<bf16_t>(Mc * dp);
     h->dpre = b.take<bf16_t>(Mc * ffmax);
-    h->dqkv = b.take<bf16_t>(Mc * 3 * d);
+    h->dqkv = b.take<bf16_t>(Mc * h->cross.qp);
     h->dorow = b.take<bf16_t>(rowmax);
     h->dsum = b.take<float>(lsemax);
     h->ln_ws = b.take<float>(ln_bwd_ws_floats((int)Mc, d));
@@ -449,6 +458,7 @@ int adam_bucket(FactHandle* h, int b, hipStream_t s) {
   return refresh_bucket(h, b, s);
 }
 
+int g_op_ln_ws = 0;            // bench knob (fact_debug_ln_bwd)
 int g_force_generic_gemm = 0;  // test knob (fact_debug_force_generic_gemm)
 
 GemmParams gp(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K) {
@@ -513,6 +523,7 @@ AttnParams attn_params(const Stack& st, const LayerA& a, int B) {
   ap.qrow = a.row[0]; ap.krow = a.row[1]; ap.vrow = a.row[2];
   ap.out = a.a; ap.o = a.a; ap.lse2 = a.lse2;
   ap.B = B; ap.H = st.H; ap.n = st.n; ap.NP = st.NP; ap.hid = st.d; ap.dh = st.dh;
+  ap.ldo = st.dp; ap.ldq = st.qp;
   ap.scale = 1.0f / sqrtf((float)st.d);  // dim**-0.5 with dim = hidden_size (base_models.py:66,104)
   return ap;
 }
@@ -533,29 +544,29 @@ hipEvent_t stream_after(FactHandle* h, hipStream_t from, hipStream_t to) {
 hipStream_t side_of(FactHandle* h, hipStream_t s) { return (h->use_side && h->side) ? h->side : s; }
 
 int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
-  const int M = B * st.n, d = st.d;
+  const int M = B * st.n, d = st.d, dp = st.dp, fp = st.fp;
   LayerP& p = st.lp[l];
   LayerA& a = st.la[l];
-  CHK(launch_ln_fwd(a.x_in, P(h, p.ln1_g), P(h, p.ln1_b), a.h1, a.mean1, a.rstd1, M, d, h->cfg.ln_eps, s));
+  CHK(launch_ln_fwd(a.x_in, P(h, p.ln1_g), P(h, p.ln1_b), a.h1, dp, a.mean1, a.rstd1, M, d, h->cfg.ln_eps, s));
   {
-    GemmParams g = gp(a.h1, d, p.wqkv.t, p.wqkv.ldt, M, 3 * d, d);
+    GemmParams g = gp(a.h1, dp, p.wqkv.t, p.wqkv.ldt, M, 3 * d, d);
     heads_ep(g.ep, st, a.row, 3);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
   CHK(launch_attn_fwd(attn_params(st, a, B), s));
   {
-    GemmParams g = gp(a.a, d, p.wo.t, p.wo.ldt, M, d, d);
+    GemmParams g = gp(a.a, dp, p.wo.t, p.wo.ldt, M, d, d);
     g.ep.out0 = a.x_mid; g.ep.ldo0 = d; g.ep.bias = P(h, p.bo); g.ep.resid = a.x_in; g.ep.ldr = d;
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
-  CHK(launch_ln_fwd(a.x_mid, P(h, p.ln2_g), P(h, p.ln2_b), a.h2, a.mean2, a.rstd2, M, d, h->cfg.ln_eps, s));
+  CHK(launch_ln_fwd(a.x_mid, P(h, p.ln2_g), P(h, p.ln2_b), a.h2, dp, a.mean2, a.rstd2, M, d, h->cfg.ln_eps, s));
   {
-    GemmParams g = gp(a.h2, d, p.w1.t, p.w1.ldt, M, st.ff, d);
-    g.ep.out0 = a.pre; g.ep.ldo0 = st.ff; g.ep.out1 = a.g; g.ep.ldo1 = st.ff; g.ep.bias = P(h, p.b1);
+    GemmParams g = gp(a.h2, dp, p.w1.t, p.w1.ldt, M, st.ff, d);
+    g.ep.out0 = a.pre; g.ep.ldo0 = fp; g.ep.out1 = a.g; g.ep.ldo1 = fp; g.ep.bias = P(h, p.b1);
     CHK(launch_gemm_nt(EPI_BIAS_GELU, g, s));
   }
   {
-    GemmParams g = gp(a.g, st.ff, p.w2.t, p.w2.ldt, M, d, st.ff);
+    GemmParams g = gp(a.g, fp, p.w2.t, p.w2.ldt, M, d, st.ff);
     g.ep.out0 = a.x_out; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = a.x_mid; g.ep.ldr = d;
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
@@ -564,7 +575,7 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
 
 // On entry dx / dx16 hold dL/dx_out of layer l; on exit dL/dx_in.
 int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx16, hipStream_t s) {
-  const int M = B * st.n, d = st.d, ff = st.ff;
+  const int M = B * st.n, d = st.d, ff = st.ff, dp = st.dp, fp = st.fp, qp = st.qp;
   LayerP& p = st.lp[l];
   LayerA& a = st.la[l];
   // The wgrad GEMMs (and the b1 column sum) go to the side stream; the dgrad / attention / LayerNorm
@@ -574,32 +585,32 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx
   const bool two = (w != s);
   // ---- MLP block: x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
   if (two) stream_after(h, s, w);  // dx16 ready
-  CHK(wgrad(h, a.g, ff, ff, dx16, d, d, M, G(h, p.w2.w), d, w));
+  CHK(wgrad(h, a.g, fp, ff, dx16, dp, d, M, G(h, p.w2.w), d, w));
   hipEvent_t e_w2 = two ? stream_mark(h, w) : nullptr;
   if (two && h->ev_dpre_free) (void)hipStreamWaitEvent(s, h->ev_dpre_free, 0);
   {
-    GemmParams g = gp(dx16, d, p.w2.s, p.w2.lds, M, ff, d);
-    g.ep.out0 = h->dpre; g.ep.ldo0 = ff; g.ep.pre = a.pre; g.ep.ldp = ff;
+    GemmParams g = gp(dx16, dp, p.w2.s, p.w2.lds, M, ff, d);
+    g.ep.out0 = h->dpre; g.ep.ldo0 = fp; g.ep.pre = a.pre; g.ep.ldp = fp;
     CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
   }
   if (two) stream_after(h, s, w);  // dpre ready
-  CHK(wgrad(h, a.h2, d, d, h->dpre, ff, ff, M, G(h, p.w1.w), ff, w));
-  CHK(launch_colsum_bf16(h->dpre, ff, G(h, p.b1), M, ff, ff, w));
+  CHK(wgrad(h, a.h2, dp, d, h->dpre, fp, ff, M, G(h, p.w1.w), ff, w));
+  CHK(launch_colsum_bf16(h->dpre, fp, G(h, p.b1), M, ff, ff, w));
   if (two) h->ev_dpre_free = stream_mark(h, w);
   {
-    GemmParams g = gp(h->dpre, ff, p.w1.s, p.w1.lds, M, d, ff);
-    g.ep.out0 = h->dh; g.ep.ldo0 = d;
+    GemmParams g = gp(h->dpre, fp, p.w1.s, p.w1.lds, M, d, ff);
+    g.ep.out0 = h->dh; g.ep.ldo0 = dp;
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
   if (two) (void)hipStreamWaitEvent(s, e_w2, 0);  // wgrad W2 finished reading dx16
   CHK(launch_ln_bwd(h->dh, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, dx16, G(h, p.ln2_g),
-                    G(h, p.ln2_b), G(h, p.b2), h->ln_ws, M, d, s));
+                    G(h, p.ln2_b), G(h, p.b2), h->ln_ws, M, d, dp, s));
   // ---- attention block: x_mid = x_in + Wo attn(Wqkv LN1(x_in)) + bo
   if (two) stream_after(h, s, w);  // new dx16 ready
-  CHK(wgrad(h, a.a, d, d, dx16, d, d, M, G(h, p.wo.w), d, w));
+  CHK(wgrad(h, a.a, dp, d, dx16, dp, d, M, G(h, p.wo.w), d, w));
   hipEvent_t e_wo = two ? stream_mark(h, w) : nullptr;
   {
-    GemmParams g = gp(dx16, d, p.wo.s, p.wo.lds, M, d, d);
+    GemmParams g = gp(dx16, dp, p.wo.s, p.wo.lds, M, d, d);
     bf16_t* row[1] = {h->dorow};
     heads_ep(g.ep, st, row, 1);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
@@ -611,16 +622,16 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx
     CHK(launch_attn_bwd(ap, s));
   }
   if (two) stream_after(h, s, w);  // dqkv ready
-  CHK(wgrad(h, a.h1, d, d, h->dqkv, 3 * d, 3 * d, M, G(h, p.wqkv.w), 3 * d, w));
+  CHK(wgrad(h, a.h1, dp, d, h->dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w));
   if (two) h->ev_dqkv_free = stream_mark(h, w);
   {
-    GemmParams g = gp(h->dqkv, 3 * d, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
-    g.ep.out0 = h->dh; g.ep.ldo0 = d;
+    GemmParams g = gp(h->dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
+    g.ep.out0 = h->dh; g.ep.ldo0 = dp;
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
   if (two) (void)hipStreamWaitEvent(s, e_wo, 0);  // wgrad Wo finished reading dx16
   CHK(launch_ln_bwd(h->dh, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, dx16, G(h, p.ln1_g),
-                    G(h, p.ln1_b), G(h, p.bo), h->ln_ws, M, d, s));
+                    G(h, p.ln1_b), G(h, p.bo), h->ln_ws, M, d, dp, s));
   return 0;
 }
 
@@ -638,7 +649,7 @@ int embed_backward(FactHandle* h, Stack& st, int B, float* dx, bf16_t* dx16, hip
   const int M = B * st.n;
   hipStream_t w = side_of(h, s);  // all wgrads share the side stream (and its transpose scratch)
   if (w != s) stream_after(h, s, w);
-  CHK(wgrad(h, st.xin16, st.featp, st.feat, dx16, st.d, st.d, M, G(h, st.emb.w), st.d, w));
+  CHK(wgrad(h, st.xin16, st.featp, st.feat, dx16, st.dp, st.d, M, G(h, st.emb.w), st.d, w));
   CHK(launch_colsum_f32(dx, st.d, G(h, st.emb_b), M, st.d, st.d, s));
   CHK(launch_possum(dx, G(h, st.pos), B, st.n, st.d, s));
   return 0;
@@ -863,8 +874,8 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
 static int head_forward(FactHandle* h, int B, float* out, hipStream_t s) {
   Stack& cr = h->cross;
   const int Mc = B * cr.n;
-  CHK(launch_cast_bf16(cr.out(), h->xf16, (size_t)Mc * cr.d, s));
-  GemmParams g = gp(h->xf16, cr.d, h->head.t, h->head.ldt, Mc, h->cfg.out_dim, cr.d);
+  CHK(launch_pad_cast(cr.out(), Mc, 0, Mc, cr.d, h->xf16, cr.dp, s));
+  GemmParams g = gp(h->xf16, cr.dp, h->head.t, h->head.ldt, Mc, h->cfg.out_dim, cr.d);
   g.ep.out0 = out; g.ep.ldo0 = h->cfg.out_dim; g.ep.bias = P(h, h->head_b);
   CHK(launch_gemm_nt(EPI_F32_BIAS, g, s));
   return 0;
@@ -900,12 +911,12 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   {
     hipStream_t w = side_of(h, s);
     if (w != s) stream_after(h, s, w);
-    CHK(wgrad(h, h->xf16, d, d, h->dpred, h->outp, D, Mc, G(h, h->head.w), D, w));
+    CHK(wgrad(h, h->xf16, cr.dp, d, h->dpred, h->outp, D, Mc, G(h, h->head.w), D, w));
   }
   CHK(launch_colsum_bf16(h->dpred, h->outp, G(h, h->head_b), Mc, h->outp, D, s));
   {
     GemmParams g = gp(h->dpred, h->outp, h->head.s, h->head.lds, Mc, d, h->outp);
-    g.ep.out0 = h->dx; g.ep.ldo0 = d; g.ep.out1 = h->dx16; g.ep.ldo1 = d;
+    g.ep.out0 = h->dx; g.ep.ldo0 = d; g.ep.out1 = h->dx16; g.ep.ldo1 = cr.dp;
     CHK(launch_gemm_nt(EPI_F32_BF16, g, s));
   }
   // Gradient buckets are contiguous arena ranges reported in the order they become final:
@@ -916,7 +927,7 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
     CHK(layer_backward(h, cr, l, B, h->dx, h->dx16, s));
     CHK(notify_grads(h, s));  // cross layer l
   }
-  CHK(launch_split_grad(h->dx, B, mo.n, au.n, d, h->dxm, h->dxm16, h->dxa, h->dxa16, s));
+  CHK(launch_split_grad(h->dx, B, mo.n, au.n, d, h->dxm, h->dxm16, h->dxa, h->dxa16, cr.dp, s));
   for (int l = au.L - 1; l >= 0; --l) CHK(layer_backward(h, au, l, B, h->dxa, h->dxa16, s));
   CHK(embed_backward(h, au, B, h->dxa, h->dxa16, s));
   CHK(notify_grads(h, s));  // audio stack
@@ -1083,17 +1094,58 @@ int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int 
   return 0;
 }
 
+int fact_op_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, const void* const* B,
+                            const int* ldb, const int* Mo, const int* No, float* const* out,
+                            const int* ldo, int K, int max_wgs, void* scratch, size_t scratch_bytes,
+                            size_t* scratch_needed, void* stream) {
+  if (nprob < 1 || nprob > TN_MAX_PROB) return fail(-1, "nprob outside [1, 6]");
+  TnGroupParams p;
+  memset(&p, 0, sizeof(p));
+  p.nprob = nprob;
+  p.K = K;
+  for (int q = 0; q < nprob; ++q) {
+    p.pr[q].A = (const bf16_t*)A[q]; p.pr[q].lda = lda[q];
+    p.pr[q].B = (const bf16_t*)B[q]; p.pr[q].ldb = ldb[q];
+    p.pr[q].out = out ? out[q] : nullptr; p.pr[q].ldo = ldo[q];
+    p.pr[q].Mo = Mo[q]; p.pr[q].No = No[q];
+  }
+  const size_t need = tn_grouped_slab_floats(p, max_wgs) * sizeof(float);
+  if (scratch_needed) *scratch_needed = need;
+  if (!scratch) return need ? 0 : fail(-1, "invalid grouped wgrad problem");
+  if (!need || scratch_bytes < need) return fail(-1, "grouped wgrad scratch too small");
+  p.slab = (float*)scratch;
+  CHK(launch_gemm_tn_grouped(p, max_wgs, (hipStream_t)stream));
+  return 0;
+}
+
 int fact_op_ln_fwd(const float* x, const float* gamma, const float* beta, void* hh, float* mean,
                    float* rstd, int M, int C, float eps, void* stream) {
-  CHK(launch_ln_fwd(x, gamma, beta, (bf16_t*)hh, mean, rstd, M, C, eps, (hipStream_t)stream));
+  CHK(launch_ln_fwd(x, gamma, beta, (bf16_t*)hh, C, mean, rstd, M, C, eps, (hipStream_t)stream));
   return 0;
 }
 
 int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
                    const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
                    float* dbeta, float* dbias_prev, int M, int C, void* stream) {
+  float* ws = nullptr;
+  if (g_op_ln_ws) {  // bench knob: the engine's partial-sum path (workspace owned by the op)
+    static float* buf = nullptr;
+    static size_t cap = 0;
+    const size_t need = ln_bwd_ws_floats(M, C);
+    if (need > cap) {
+      if (buf) hipFree(buf);
+      if (hipMalloc(&buf, need * sizeof(float)) != hipSuccess) return fail(-20, "ln ws alloc");
+      cap = need;
+    }
+    ws = buf;
+  }
   CHK(launch_ln_bwd((const bf16_t*)dh, x, mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, dgamma, dbeta,
-                    dbias_prev, nullptr, M, C, (hipStream_t)stream));
+                    dbias_prev, ws, M, C, C, (hipStream_t)stream));
+  return 0;
+}
+int fact_debug_ln_bwd(int rows_per_block, int use_ws) {
+  if (rows_per_block >= 4 && (rows_per_block & 3) == 0) ln_set_bwd_rows(rows_per_block);
+  g_op_ln_ws = use_ws;
   return 0;
 }
 
@@ -1152,6 +1204,7 @@ int fact_op_attention(const void* qkv, int B, int H, int n, int dh, float scale,
   ap.qrow = row[0]; ap.krow = row[1]; ap.vrow = row[2];
   ap.out = (bf16_t*)out; ap.o = (const bf16_t*)out; ap.lse2 = (float*)(sc + L.lse);
   ap.B = B; ap.H = H; ap.n = n; ap.NP = st.NP; ap.hid = hid; ap.dh = dh; ap.scale = scale;
+  ap.ldo = hid; ap.ldq = 3 * hid;
   int rc = launch_attn_fwd(ap, s);
   if (rc == 0 && dout) {
     GemmParams g = gp((const bf16_t*)dout, hid, eye, W, M, hid, hid);
@@ -1179,6 +1232,10 @@ int fact_debug_attn_force_tiled(int on) {
 }
 int fact_debug_gemm_nt_variant(int v) {
   gemm_set_nt_variant(v);
+  return 0;
+}
+int fact_debug_gemm_nt_band(int band) {
+  gemm_set_nt_band(band);
   return 0;
 }
 

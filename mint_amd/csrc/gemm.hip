@@ -183,8 +183,19 @@ DEVINL BlockCoord block_coord(const GemmParams& p) {
   BlockCoord c;
   c.z = id % p.splitk;
   const int t = id / p.splitk;
-  c.n0 = (t % tn) * BN;
-  c.m0 = (t / tn) * BM;
+  if (p.band > 1) {
+    // bands of `band` m-tiles, m fastest inside a band: the ~64 tiles an XCD runs at once form a
+    // near-square patch, so they share band + 64/band operand slabs per K step instead of tn + 64/tn
+    const int tm = (p.M + BM - 1) / BM;
+    const int per = p.band * tn;
+    const int b = t / per, w = t - b * per;
+    const int hb = min(p.band, tm - b * p.band);
+    c.m0 = (b * p.band + w % hb) * BM;
+    c.n0 = (w / hb) * BN;
+  } else {
+    c.n0 = (t % tn) * BN;
+    c.m0 = (t / tn) * BM;
+  }
   return c;
 }
 
@@ -210,6 +221,80 @@ DEVINL bf16x8 nt_frag(const unsigned char* tile, int row, int chunk) {
 // TN fragment via the LDS transpose read: for k-slot group g = lane>>4, lane s = lane&15 supplies
 // the address of 4 contiguous m-elements of row k = g*8 + hh*4 + (s>>2), columns (s&3)*4..+3; the
 // hardware hands lane c the 4 k-values of column c (verified by tests/test_gpu_ops.py probe).
+//
+// The read is issued as inline asm: hipcc puts a full `s_waitcnt vmcnt(0)` in front of the
+// __builtin_amdgcn_ds_read_tr16_b64 builtin whenever an LDS-DMA load is in flight (it cannot tell the
+// two LDS buffers apart), which serialises the next stage's DMA with this stage's MFMAs.  The asm form
+// is invisible to that pass; its completion is tracked by hand (tn_wait_lds + sched_barrier).
+template <int OFF>
+DEVINL bf16x4 tr_read(unsigned addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+template <int N>
+DEVINL void tn_wait_lds() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+DEVINL unsigned lds_addr(const unsigned char* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+// Per-lane byte offset (inside a [64 k][ROWB bytes] operand tile) of unit u's fragment reads:
+//   k = ks*32 + g*8 + hh*4 + (s>>2);  f(k) = (s>>2)&3 | (g&1)<<2 does not depend on ks / hh, so
+//   offset(u, ks, hh) = lane_part + ((u ^ f) << 5) + ks*32*ROWB + hh*4*ROWB  (the last two are immediates).
+template <int ROWB>
+DEVINL unsigned tn_lane_off(int u, int lane) {
+  const int g = lane >> 4, s = lane & 15;
+  const int f = ((s >> 2) & 3) | ((g & 1) << 2);
+  return (unsigned)((g * 8 + (s >> 2)) * ROWB + (s & 3) * 8 + ((u ^ f) << 5));
+}
+template <int ROWB, int KS>
+DEVINL bf16x8 tn_frag_at(unsigned addr) {
+  const bf16x4 lo = tr_read<KS * 32 * ROWB>(addr);
+  const bf16x4 hi = tr_read<KS * 32 * ROWB + 4 * ROWB>(addr);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// One 128x128x64 TN stage: the transpose reads of both 32-deep sub-steps are issued up front (30 of 32:
+// lgkmcnt saturates at 15), the first sub-step's MFMAs start when its 16 reads have landed, the second's
+// reads complete underneath them.
+template <bool SWAP>
+DEVINL void compute_tile_tn(const unsigned char* As, const unsigned char* Bs, f32x4 (&acc)[4][4], int wm, int wn,
+                            int lane) {
+  const unsigned a0 = lds_addr(As), b0 = lds_addr(Bs);
+  unsigned aa[4], ba[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    aa[i] = a0 + tn_lane_off<256>(wm * 4 + i, lane);
+    ba[i] = b0 + tn_lane_off<256>(wn * 4 + i, lane);
+  }
+  bf16x8 af0[4], bf0[4], af1[4], bf1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af0[i] = tn_frag_at<256, 0>(aa[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) bf0[i] = tn_frag_at<256, 0>(ba[i]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af1[i] = tn_frag_at<256, 1>(aa[i]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) bf1[i] = tn_frag_at<256, 1>(ba[i]);
+  tn_wait_lds<14>();  // lgkmcnt is a 4-bit in-order counter: <= 14 outstanding <=> the 16 sub-step-0 reads landed
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc[i][j] = SWAP ? mfma16(bf0[j], af0[i], acc[i][j]) : mfma16(af0[i], bf0[j], acc[i][j]);
+  __builtin_amdgcn_sched_barrier(0);  // keep the sub-step-0 MFMAs above the second wait
+  bf1[3] = tn_frag_at<256, 1>(ba[3]);
+  tn_wait_lds<0>();
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      acc[i][j] = SWAP ? mfma16(bf1[j], af1[i], acc[i][j]) : mfma16(af1[i], bf1[j], acc[i][j]);
+}
+
+// builtin form, kept for the generic (register-staged, no LDS-DMA in flight) kernel
 DEVINL bf16x8 tn_frag(const unsigned char* tile, int ks, int u, int lane) {
   const int g = lane >> 4, s = lane & 15;
   bf16x4 r[2];
@@ -493,12 +578,155 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast_kernel(const GemmParams p
   for (int kt = kt_beg; kt < kt_end; ++kt) {
     if (kt + 1 < kt_end) stage(buf ^ 1, kt + 1);
     const unsigned char* As = smem + buf * 2 * TILE_BYTES;
-    compute_tile<true, kSwap<EPI>>(As, As + TILE_BYTES, acc, 2, wm, wn, lane);
+    compute_tile_tn<kSwap<EPI>>(As, As + TILE_BYTES, acc, wm, wn, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     buf ^= 1;
   }
   run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, bc.z);
+}
+
+// ------------------------------------------------------------------------------------------
+// grouped, K-balanced TN (see gemm.h): same 128x128x64 LDS-DMA / transpose-read body as the fast TN
+// kernel; a workgroup walks its unit range [w*per, (w+1)*per) and emits one partial tile per segment.
+// Segment id of the segment that starts at unit u (u is a multiple of kiters or of per):
+//   id(u) = u/kiters + u/per - u/lcm(kiters, per)   (= number of segment boundaries in (0, u]).
+// Partial tiles are stored lane-major (slot (i*4+j), thread) so the stores are 1 KiB contiguous per
+// wave instruction; the reduce kernel undoes the MFMA layout.
+// ------------------------------------------------------------------------------------------
+DEVINL int seg_id(int u, int kiters, int per, int lcm) { return u / kiters + u / per - u / lcm; }
+
+struct TnTileCtx {  // per-lane DMA source pointers of the NEXT K step to stage, and their per-step strides
+  const bf16_t* ap[4];
+  const bf16_t* bp[4];
+  size_t astep, bstep;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int w;
+  {  // XCD-contiguous re-deal of the workgroup index (see block_coord)
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int u0 = w * p.per;
+  const int uend = min(u0 + p.per, p.total);
+  if (u0 >= uend) return;
+  const int lk = lane >> 4, lp = lane & 15;
+
+  auto decode = [&](int tg, int kt, TnTileCtx& c) {
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < TN_MAX_PROB; ++i)
+      if (i < p.nprob && tg >= p.pr[i].tile_begin) q = i;
+    const bf16_t* A = p.pr[q].A;
+    const bf16_t* B = p.pr[q].B;
+    const int lda = p.pr[q].lda, ldb = p.pr[q].ldb;
+    const int t = tg - p.pr[q].tile_begin;
+    const int m0 = (t / p.pr[q].tn) * BM, n0 = (t % p.pr[q].tn) * BN;
+    c.astep = (size_t)BK * lda;
+    c.bstep = (size_t)BK * ldb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kr = (wave * 4 + i) * 4 + lk;  // row inside a 64-deep K step
+      const int mc = ((((lp >> 1) ^ tn_f(kr)) << 1) | (lp & 1)) * 8;
+      const size_t k = (size_t)kt * BK + kr;
+      c.ap[i] = A + k * lda + min(m0 + mc, lda - 8);
+      c.bp[i] = B + k * ldb + min(n0 + mc, ldb - 8);
+    }
+  };
+  auto stage = [&](int buf, TnTileCtx& c) {
+    unsigned char* As = smem + buf * 2 * TILE_BYTES + wave * 4096;
+    unsigned char* Bs = As + TILE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      glds16(c.ap[i], As + i * 1024);
+      glds16(c.bp[i], Bs + i * 1024);
+      c.ap[i] += c.astep;
+      c.bp[i] += c.bstep;
+    }
+  };
+
+  // One software pipeline over the whole unit range: the first K step of the next tile is already in
+  // flight while the last step of the current tile is multiplied and its partial tile is stored.
+  TnTileCtx ctx;
+  int tg = u0 / p.kiters;
+  int kt = u0 - tg * p.kiters;
+  int seg_start = u0;
+  decode(tg, kt, ctx);
+  f32x4 acc[4][4];
+  zero_acc(acc);
+  stage(0, ctx);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int buf = 0;
+  for (int u = u0; u < uend; ++u) {
+    const bool tile_end = (kt + 1 == p.kiters);
+    if (u + 1 < uend) {
+      if (tile_end) decode(tg + 1, 0, ctx);
+      stage(buf ^ 1, ctx);
+    }
+    const unsigned char* As = smem + buf * 2 * TILE_BYTES;
+    compute_tile_tn<true>(As, As + TILE_BYTES, acc, wm, wn, lane);
+    if (tile_end || u + 1 == uend) {
+      float4* dst =
+          reinterpret_cast<float4*>(p.slab + (size_t)seg_id(seg_start, p.kiters, p.per, p.lcm) * (BM * BN)) + tid;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          dst[(i * 4 + j) * 256] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      zero_acc(acc);
+      seg_start = u + 1;
+    }
+    if (tile_end) { tg += 1; kt = 0; } else { kt += 1; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    buf ^= 1;
+  }
+}
+
+// grid (ntiles, 4): block (tg, part) sums slots part*4 .. part*4+3 of every segment of tile tg
+__global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(const TnGroupParams p) {
+  const int tg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < TN_MAX_PROB; ++i)
+    if (i < p.nprob && tg >= p.pr[i].tile_begin) q = i;
+  const int t = tg - p.pr[q].tile_begin;
+  const int m0 = (t / p.pr[q].tn) * BM, n0 = (t % p.pr[q].tn) * BN;
+  const int Mo = p.pr[q].Mo, No = p.pr[q].No, ldo = p.pr[q].ldo;
+  float* out = p.pr[q].out;
+  const int s0 = seg_id(tg * p.kiters, p.kiters, p.per, p.lcm);
+  const int s1 = seg_id((tg + 1) * p.kiters - 1, p.kiters, p.per, p.lcm);
+#pragma unroll
+  for (int ss = 0; ss < 4; ++ss) {
+    const int slot = blockIdx.y * 4 + ss;
+    const int i = slot >> 2, j = slot & 3;
+    const int row = m0 + wm * 64 + i * 16 + (lane & 15);
+    const int col0 = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+    if (row >= Mo || col0 >= No) continue;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int sgi = s0; sgi <= s1; ++sgi) {
+      const float4 v = reinterpret_cast<const float4*>(p.slab + (size_t)sgi * (BM * BN))[slot * 256 + tid];
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float* o = out + (size_t)row * ldo + col0;
+    if (col0 + 3 < No && !(ldo & 3)) {
+      float4 c = *reinterpret_cast<float4*>(o);
+      c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
+      *reinterpret_cast<float4*>(o) = c;
+    } else {
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col0 + r < No) o[r] += av[r];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -688,10 +916,13 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(const GemmParams p
   run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, bc.z);
 }
 
+int g_nt_band = 8;  // tile band height of the NT kernels (bench knob; measured: 8 >= 4 > row-major)
 int g_nt_variant = 0;  // 0 auto, 1 two-stage fast, 2 ring 128x128, 3 ring 256x128 (bench/test knob)
 
 template <int EPI>
-int launch_nt_t(const GemmParams& p, hipStream_t s) {
+int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
+  GemmParams p = p_in;
+  if (p.band == 0) p.band = g_nt_band;
   const int tn = (p.N + BN - 1) / BN;
   const int tiles128 = tn * ((p.M + 127) / 128), tiles256 = tn * ((p.M + 255) / 256);
   if (p.force_generic || (p.K & 31)) {
@@ -740,7 +971,50 @@ int check_common(const GemmParams& p, int epi) {
 
 }  // namespace
 
+namespace {
+int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+int tn_group_plan(TnGroupParams& p, int max_wgs) {
+  if (p.nprob < 1 || p.nprob > TN_MAX_PROB || p.K <= 0 || (p.K & 63) || max_wgs < 1) return -1;
+  int tiles = 0;
+  for (int q = 0; q < p.nprob; ++q) {
+    TnProblem& r = p.pr[q];
+    if (r.Mo <= 0 || r.No <= 0 || (r.lda & 7) || (r.ldb & 7) || r.lda < 8 || r.ldb < 8) return -2;
+    if (((uintptr_t)r.A & 15) || ((uintptr_t)r.B & 15) || ((uintptr_t)r.out & 3)) return -5;
+    r.tn = (r.No + BN - 1) / BN;
+    r.tile_begin = tiles;
+    tiles += r.tn * ((r.Mo + BM - 1) / BM);
+  }
+  p.ntiles = tiles;
+  p.kiters = p.K / BK;
+  const long long total = (long long)tiles * p.kiters;
+  if (total > (1ll << 30)) return -3;
+  p.total = (int)total;
+  p.per = (int)((total + max_wgs - 1) / max_wgs);
+  const long long l = (long long)p.kiters / gcd_i(p.kiters, p.per) * p.per;
+  p.lcm = l > (1ll << 30) ? (1 << 30) : (int)l;
+  return 0;
+}
+}  // namespace
+
+size_t tn_grouped_slab_floats(const TnGroupParams& p_in, int max_wgs) {
+  TnGroupParams p = p_in;
+  if (tn_group_plan(p, max_wgs)) return 0;
+  const int wgs = (p.total + p.per - 1) / p.per;
+  return (size_t)(p.ntiles + wgs) * BM * BN;  // upper bound on the number of segments
+}
+
+int launch_gemm_tn_grouped(TnGroupParams& p, int max_wgs, hipStream_t s) {
+  int rc = tn_group_plan(p, max_wgs);
+  if (rc) return rc;
+  if (!p.slab || ((uintptr_t)p.slab & 15)) return -5;
+  const int wgs = (p.total + p.per - 1) / p.per;
+  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(wgs), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(tn_grouped_reduce_kernel, dim3(p.ntiles, 4), dim3(256), 0, s, p);
+  return 0;
+}
+
 void gemm_set_nt_variant(int v) { g_nt_variant = v; }
+void gemm_set_nt_band(int band) { g_nt_band = band; }
 
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t s) {
   int rc = check_common(p, epi);

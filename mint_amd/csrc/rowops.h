@@ -3,20 +3,24 @@
 #include "common.h"
 
 // LayerNorm forward (eps inside the rsqrt, biased variance; mint/core/base_models.py:27).
-// x f32 [M][C] -> h bf16 [M][C]; saves mean/rstd f32 [M].  C % 4 == 0, C <= 2048.
-int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t* h, float* mean,
+// x f32 [M][C] -> h bf16 [M][ldh]; saves mean/rstd f32 [M].  C % 4 == 0, C <= 2048.
+// (bf16 activations use a row pitch that is a multiple of 64 elements so that every 128-byte K-step
+//  chunk a GEMM stages is exactly one cache line.)
+int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t* h, int ldh, float* mean,
                   float* rstd, int M, int C, float eps, hipStream_t s);
 
 // LayerNorm backward fused with the residual-gradient add:
 //   dx = dres + LNbwd(dh);  dgamma += sum_rows dh*xhat;  dbeta += sum_rows dh;
 //   dbias_prev += sum_rows dres (bias gradient of the GEMM whose output fed this residual add).
-// dx may alias dres.  dx_bf16 / dbias_prev / dres may be null.
+// dx may alias dres.  dx_bf16 / dbias_prev / dres may be null.  dh and dx_bf16 are bf16 with row
+// pitch ld16; everything else is dense f32 [M][C].
 // `ws` (>= ln_bwd_ws_floats(M, C) floats, or null) holds per-block partial column sums that a second
 // tiny kernel reduces; with ws == null the partials are accumulated with atomics instead.
 size_t ln_bwd_ws_floats(int M, int C);
+void ln_set_bwd_rows(int rows_per_block);  // tuning knob (multiple of 4, >= 8 keeps ws sizing valid)
 int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const float* rstd,
                   const float* gamma, const float* dres, float* dx, bf16_t* dx_bf16, float* dgamma,
-                  float* dbeta, float* dbias_prev, float* ws, int M, int C, hipStream_t s);
+                  float* dbeta, float* dbias_prev, float* ws, int M, int C, int ld16, hipStream_t s);
 
 // out[c] += sum_m in[m][c]   (bf16 or f32 input), C % 8 == 0 for bf16, % 4 for f32
 // only columns < Cout are accumulated into out
@@ -61,7 +65,7 @@ int launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
 int launch_concat_seq(const float* a, const float* b, int B, int na, int nb, int C, float* out, hipStream_t s);
 // split the cross-modal gradient (B, na+nb, C) into the two encoder gradients (f32 + bf16 copies)
 int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, bf16_t* da16,
-                      float* db, bf16_t* db16, hipStream_t s);
+                      float* db, bf16_t* db16, int ld16, hipStream_t s);
 // out[i] += sum_z slabs[z*stride + i], i < n (split-K partials -> gradient); stride % 4 == 0
 int launch_slab_reduce(const float* slabs, size_t stride, int nslab, float* out, size_t n, hipStream_t s);
 // sum of squares of a flat f32 buffer -> out[0] (atomicAdd), and flat scale

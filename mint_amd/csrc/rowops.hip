@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ gamma,
                                                      const float* __restrict__ beta,
                                                      bf16_t* __restrict__ h, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int M, int C, float eps) {
+                                                     float* __restrict__ rstd, int M, int C, int ldh, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
   const float4* b4 = reinterpret_cast<const float4*>(beta);
-  bf16x4* hr = reinterpret_cast<bf16x4*>(h + (size_t)row * C);
+  bf16x4* hr = reinterpret_cast<bf16x4*>(h + (size_t)row * ldh);
 #pragma unroll
   for (int i = 0; i < LN_MAXV; ++i) {
     const int idx = lane + i * 64;
@@ -58,14 +58,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // Each block handles LN_BWD_ROWS rows (4 waves x LN_BWD_ROWS/4 rows); per-lane column partials
 // of dgamma/dbeta/dbias are reduced across the 4 waves in LDS, then one atomicAdd per column.
-constexpr int LN_BWD_ROWS = 8;
+int g_ln_bwd_rows = 8;  // rows per block (multiple of 4); fact_debug_ln_bwd_rows
 
 template <int MAXV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const bf16_t* __restrict__ dh, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* dres, float* dx,
     bf16_t* __restrict__ dx16, float* __restrict__ dgamma, float* __restrict__ dbeta,
-    float* __restrict__ dbias_prev, float* __restrict__ part, int M, int C) {
+    float* __restrict__ dbias_prev, float* __restrict__ part, int M, int C, int ld16, int rpb) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [3][4 waves][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv = C >> 2;
@@ -80,13 +80,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const int idx = lane + i * 64;
     gm[i] = (idx < nv) ? g4[idx] : ag[i];
   }
-  const int row_beg = blockIdx.x * LN_BWD_ROWS;
-  for (int rr = wave; rr < LN_BWD_ROWS; rr += 4) {
+  const int row_beg = blockIdx.x * rpb;
+  for (int rr = wave; rr < rpb; rr += 4) {
     const int row = row_beg + rr;
     if (row >= M) break;
     const float mu = mean[row], rs = rstd[row];
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
-    const bf16x4* dhr = reinterpret_cast<const bf16x4*>(dh + (size_t)row * C);
+    const bf16x4* dhr = reinterpret_cast<const bf16x4*>(dh + (size_t)row * ld16);
     float4 xh[MAXV], dy[MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     s2 = wave_sum(s2) * invC;
     const float4* rr4 = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * C) : nullptr;
     float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * C);
-    bf16x4* dx16r = dx16 ? reinterpret_cast<bf16x4*>(dx16 + (size_t)row * C) : nullptr;
+    bf16x4* dx16r = dx16 ? reinterpret_cast<bf16x4*>(dx16 + (size_t)row * ld16) : nullptr;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int idx = lane + i * 64;
@@ -396,7 +396,7 @@ __global__ void concat_seq_kernel(const float4* __restrict__ a, const float4* __
   }
 }
 
-__global__ void split_grad_kernel(const float4* __restrict__ dx, int B, int na, int nb, int C4,
+__global__ void split_grad_kernel(const float4* __restrict__ dx, int B, int na, int nb, int C4, int ld4,
                                   float4* __restrict__ da, bf16x4* __restrict__ da16,
                                   float4* __restrict__ db, bf16x4* __restrict__ db16) {
   const size_t total = (size_t)B * (na + nb) * C4;
@@ -409,13 +409,13 @@ __global__ void split_grad_kernel(const float4* __restrict__ dx, int B, int na, 
     const float4 v = dx[i];
     bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
     if (t < na) {
-      const size_t j = ((size_t)b * na + t) * C4 + c;
-      da[j] = v;
-      da16[j] = o;
+      const size_t r = (size_t)b * na + t;
+      da[r * C4 + c] = v;
+      da16[r * ld4 + c] = o;
     } else {
-      const size_t j = ((size_t)b * nb + (t - na)) * C4 + c;
-      db[j] = v;
-      db16[j] = o;
+      const size_t r = (size_t)b * nb + (t - na);
+      db[r * C4 + c] = v;
+      db16[r * ld4 + c] = o;
     }
   }
 }
@@ -466,30 +466,33 @@ inline int grid_for(size_t n, int block, int cap = 4096) {
 
 }  // namespace
 
-int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t* h, float* mean,
+int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t* h, int ldh, float* mean,
                   float* rstd, int M, int C, float eps, hipStream_t s) {
-  if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0) return -1;
+  if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0 || ldh < C || (ldh & 3)) return -1;
   hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd,
-                     M, C, eps);
+                     M, C, ldh, eps);
   return 0;
 }
 
+void ln_set_bwd_rows(int r) { g_ln_bwd_rows = r < 8 ? 8 : r; }
+
 size_t ln_bwd_ws_floats(int M, int C) {
-  return (size_t)((M + LN_BWD_ROWS - 1) / LN_BWD_ROWS) * 3 * C;
+  return (size_t)((M + 7) / 8) * 3 * C;  // sized for the smallest rows-per-block (8)
 }
 
 int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const float* rstd,
                   const float* gamma, const float* dres, float* dx, bf16_t* dx_bf16, float* dgamma,
-                  float* dbeta, float* dbias_prev, float* ws, int M, int C, hipStream_t s) {
-  if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0) return -1;
-  const int grid = (M + LN_BWD_ROWS - 1) / LN_BWD_ROWS;
+                  float* dbeta, float* dbias_prev, float* ws, int M, int C, int ld16, hipStream_t s) {
+  if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0 || ld16 < C || (ld16 & 3)) return -1;
+  const int rpb = g_ln_bwd_rows;
+  const int grid = (M + rpb - 1) / rpb;
   const size_t shmem = (size_t)3 * 4 * C * sizeof(float);
   if (C <= 1024) {
     hipLaunchKernelGGL((ln_bwd_kernel<4>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
-                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, ws, M, C);
+                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, ws, M, C, ld16, rpb);
   } else {
     hipLaunchKernelGGL((ln_bwd_kernel<8>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
-                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, ws, M, C);
+                       dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, ws, M, C, ld16, rpb);
   }
   if (ws) {
     dim3 g2((3 * C + 255) / 256, (grid + 31) / 32);
@@ -585,11 +588,11 @@ int launch_concat_seq(const float* a, const float* b, int B, int na, int nb, int
 }
 
 int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, bf16_t* da16, float* db,
-                      bf16_t* db16, hipStream_t s) {
-  if (C & 3) return -1;
+                      bf16_t* db16, int ld16, hipStream_t s) {
+  if ((C & 3) || ld16 < C || (ld16 & 3)) return -1;
   const size_t total = (size_t)B * (na + nb) * (C >> 2);
   hipLaunchKernelGGL(split_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)dx,
-                     B, na, nb, C >> 2, (float4*)da, (bf16x4*)da16, (float4*)db, (bf16x4*)db16);
+                     B, na, nb, C >> 2, ld16 >> 2, (float4*)da, (bf16x4*)da16, (float4*)db, (bf16x4*)db16);
   return 0;
 }
 

@@ -14,10 +14,11 @@ SHAPES = [  # M, N, K, epi
 ]
 
 
-def run(M, N, K, epi, variant, iters=30):
+def run(M, N, K, epi, variant, iters=30, pitch=None):
     g = torch.Generator(device=dev).manual_seed(0)
-    A = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
-    B = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    ld = pitch or K
+    A = torch.randn(M, ld, device=dev, generator=g).to(torch.bfloat16)
+    B = (torch.randn(N, ld, device=dev, generator=g) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device=dev, generator=g)
     resid = torch.randn(M, N, device=dev, generator=g)
     pre = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16)
@@ -27,7 +28,7 @@ def run(M, N, K, epi, variant, iters=30):
     lib.fact_debug_gemm_nt_variant(variant)
 
     def launch():
-        L.check(lib.fact_op_gemm_nt(epi, L.ptr(A), K, L.ptr(B), K, M, N, K, L.ptr(o0), N, L.ptr(o1), N, L.ptr(bias),
+        L.check(lib.fact_op_gemm_nt(epi, L.ptr(A), ld, L.ptr(B), ld, M, N, K, L.ptr(o0), N, L.ptr(o1), N, L.ptr(bias),
                                     None, 0, L.ptr(resid), N, L.ptr(pre), N, L.cur_stream()))
     for _ in range(3):
         launch()
@@ -38,7 +39,7 @@ def run(M, N, K, epi, variant, iters=30):
     e1.record()
     e1.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
-    ref = A.float() @ B.float().t()
+    ref = A[:, :K].float() @ B[:, :K].float().t()
     if epi == L.EPI_BF16:
         err = ((o0.float() - ref).norm() / ref.norm()).item()
     elif epi == L.EPI_F32_BIAS_RESID:
@@ -51,20 +52,64 @@ def run(M, N, K, epi, variant, iters=30):
     return us, 2.0 * M * N * K / us / 1e6, err
 
 
+if len(sys.argv) > 1 and sys.argv[1] == "shape":  # ad-hoc shapes: shape M N K [M N K ...]
+    a = list(map(int, sys.argv[2:]))
+    for i in range(0, len(a), 3):
+        M, N, K = a[i:i + 3]
+        for v in map(int, os.environ.get("NT_VARIANTS", "1").split(",")):
+            lib.fact_debug_gemm_nt_band(int(os.environ.get("NT_BAND", "8")))
+            us, tf, err = run(M, N, K, L.EPI_BF16, v)
+            tiles = ((M + 127) // 128) * ((N + 127) // 128)
+            print("M%d N%d K%d v%d: %.1f us %.0f TF  tiles %d  us/k64-iter/round %.3f  err %.1e" % (
+                M, N, K, v, us, tf, tiles, us / (K / 64) / -(-tiles // 512), err))
+    sys.exit(0)
 if len(sys.argv) > 1:  # single shape/variant (for rocprofv3 --pmc runs): idx variant iters
     M, N, K, epi = SHAPES[int(sys.argv[1])]
-    us, tf, err = run(M, N, K, epi, int(sys.argv[2]), int(sys.argv[3]))
+    lib.fact_debug_gemm_nt_band(int(os.environ.get("NT_BAND", "8")))
+    us, tf, err = run(M, N, K, epi, int(sys.argv[2]), int(sys.argv[3]), pitch=int(os.environ.get("PITCH", "0")) or None)
     print("M%d N%d K%d epi%d v%s: %.1f us %.0f TF" % (M, N, K, epi, sys.argv[2], us, tf))
     sys.exit(0)
 for (M, N, K, epi) in ([] if os.environ.get("TN_ONLY") else SHAPES):
     line = "M%5d N%5d K%5d epi%d:" % (M, N, K, epi)
-    for v in (1, 3, 4):
-        us, tf, err = run(M, N, K, epi, v)
-        line += "  v%d %7.1fus %6.0fTF err %.1e" % (v, us, tf, err)
+    for (band, pitch) in ((1, None), (8, None), (4, None), (8, (K + 63) // 64 * 64)):
+        lib.fact_debug_gemm_nt_band(band)
+        us, tf, err = run(M, N, K, epi, 1, pitch=pitch)
+        line += "  b%d ld%s %6.1fus %4.0fTF %s" % (band, pitch or K, us, tf, "" if (err < 5e-3 or err != err) else "ERR %.1e" % err)
+    lib.fact_debug_gemm_nt_band(8)
     print(line, flush=True)
 
+if os.environ.get("TN_GROUP"):
+    import ctypes as C
+    for K in map(int, os.environ.get("TN_GROUP_K", "5760,3840,1920").split(",")):
+        shapes = [(3072, 800), (800, 3072), (800, 800), (800, 2400)]
+        if os.environ.get("TN_GROUP_SHAPES"):
+            v = list(map(int, os.environ["TN_GROUP_SHAPES"].split(",")))
+            shapes = [(v[i], v[i + 1]) for i in range(0, len(v), 2)]
+        pad = int(os.environ.get("TN_PAD", "8"))
+        rp = lambda x: (x + pad - 1) // pad * pad
+        As = [torch.randn(K, rp(Mo), device=dev).to(torch.bfloat16) for Mo, _ in shapes]
+        Bs = [torch.randn(K, rp(No), device=dev).to(torch.bfloat16) for _, No in shapes]
+        outs = [torch.zeros(Mo, No, device=dev) for Mo, No in shapes]
+        n = len(shapes); vp, ci = C.c_void_p * n, C.c_int * n
+        for wgs in map(int, os.environ.get("TN_GROUP_WGS", "256,512,768,1024").split(",")):
+            args = (n, vp(*[a.data_ptr() for a in As]), ci(*[a.shape[1] for a in As]), vp(*[b.data_ptr() for b in Bs]),
+                    ci(*[b.shape[1] for b in Bs]), ci(*[s[0] for s in shapes]), ci(*[s[1] for s in shapes]),
+                    vp(*[o.data_ptr() for o in outs]), ci(*[s[1] for s in shapes]), K, wgs)
+            need = C.c_size_t(0)
+            L.check(lib.fact_op_gemm_tn_grouped(*args, None, 0, C.byref(need), None))
+            scratch = torch.empty(need.value // 4, device=dev)
+            f = lambda: L.check(lib.fact_op_gemm_tn_grouped(*args, L.ptr(scratch), need.value, None, L.cur_stream()))
+            for _ in range(3): f()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): f()
+            e1.record(); e1.synchronize()
+            us = e0.elapsed_time(e1) / 20 * 1e3
+            fl = sum(2.0 * K * a * b for a, b in shapes)
+            print("grouped layer wgrad K%d wgs%d: %.1f us %.0f TF (scratch %.0f MB)" % (K, wgs, us, fl / us / 1e6, need.value / 1e6), flush=True)
+    sys.exit(0)
 print("--- TN (wgrad) ---")
-TN_SHAPES = [(5760, 800, 3072), (5760, 3072, 800), (5760, 2400, 800), (5760, 800, 800), (1920, 3072, 800), (3840, 2400, 800)]
+TN_SHAPES = [tuple(map(int, os.environ["TN_SHAPE"].split(",")))] if os.environ.get("TN_SHAPE") else [(5760, 800, 3072), (5760, 3072, 800), (5760, 2400, 800), (5760, 800, 800), (1920, 3072, 800), (3840, 2400, 800)]
 for (K, Mo, No) in TN_SHAPES:
     g = torch.Generator(device=dev).manual_seed(0)
     A = torch.randn(K, Mo, device=dev, generator=g).to(torch.bfloat16)
