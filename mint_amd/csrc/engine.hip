@@ -16,6 +16,7 @@
 #include "gemm.h"
 #include "rowops.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -103,6 +104,7 @@ struct Bump {
 struct Bucket {
   size_t off = 0, cnt = 0;  // float range in the arenas
   int desc_first = 0, desc_n = 0, tiles = 0;
+  int blk_first = 0, blk_n = 0;  // AdamBlock range of the fused optimizer + shadow-refresh kernel
 };
 struct AdamArgs {
   float lr_t = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, gscale = 1.f;
@@ -142,6 +144,8 @@ struct FactHandle {
   bf16_t *tA = nullptr, *tB = nullptr;  // transposed operands for the non-tr wgrad path
   float* ln_ws = nullptr;               // LayerNorm-backward per-block partial column sums
   CastDesc* cast_table = nullptr;       // device tables for the per-bucket weight-shadow refresh
+  AdamBlock* adam_blocks = nullptr;     // device table of the fused Adam + shadow-refresh kernel
+  int fuse_adam_cast = 1;
   std::vector<Bucket> buckets;          // gradient / optimizer buckets in backward-completion order
   AdamArgs adam;                        // hyper-parameters of the optimizer step in flight
   bool adam_pending = false;            // fact_adam_begin called: buckets are updated inside backward
@@ -436,6 +440,43 @@ int build_buckets(FactHandle* h) {
   add(mo.emb);
   HIPCHK(hipMalloc((void**)&h->cast_table, t.size() * sizeof(CastDesc)));
   HIPCHK(hipMemcpy(h->cast_table, t.data(), t.size() * sizeof(CastDesc), hipMemcpyHostToDevice));
+  // Fused Adam + shadow refresh: walk every bucket's arena range; Dense kernels become 64x64 tile
+  // blocks, everything between them (biases, LayerNorm, position tables, alignment padding) flat blocks.
+  std::vector<AdamBlock> ab;
+  for (Bucket& b : h->buckets) {
+    b.blk_first = (int)ab.size();
+    std::vector<CastDesc> ds(t.begin() + b.desc_first, t.begin() + b.desc_first + b.desc_n);
+    std::sort(ds.begin(), ds.end(), [](const CastDesc& x, const CastDesc& y) { return x.src < y.src; });
+    size_t cur = b.off;
+    auto flat = [&](size_t beg, size_t end) {
+      for (size_t o = beg; o < end; o += 4096) {
+        AdamBlock k;
+        memset(&k, 0, sizeof(k));
+        k.off = o;
+        k.C = (int)std::min<size_t>(4096, end - o);
+        ab.push_back(k);
+      }
+    };
+    for (const CastDesc& d : ds) {
+      const size_t toff = (size_t)(d.src - h->params);
+      if (toff > cur) flat(cur, toff);
+      for (int r0 = 0; r0 < d.R; r0 += 64)
+        for (int c0 = 0; c0 < d.C; c0 += 64) {
+          AdamBlock k;
+          memset(&k, 0, sizeof(k));
+          k.off = toff; k.s = d.s; k.t = d.t; k.R = d.R; k.C = d.C; k.lds = d.lds; k.ldt = d.ldt;
+          k.r0 = r0; k.c0 = c0;
+          ab.push_back(k);
+        }
+      // the tail of a Dense tensor whose size is not a multiple of 4 floats is covered by its tile
+      // blocks; flat segments resume at the next 64-float boundary (tensor offsets are 64-aligned)
+      cur = rups(toff + (size_t)d.R * d.C, 64);
+    }
+    if (b.off + b.cnt > cur) flat(cur, b.off + b.cnt);
+    b.blk_n = (int)ab.size() - b.blk_first;
+  }
+  HIPCHK(hipMalloc((void**)&h->adam_blocks, ab.size() * sizeof(AdamBlock)));
+  HIPCHK(hipMemcpy(h->adam_blocks, ab.data(), ab.size() * sizeof(AdamBlock), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -453,6 +494,9 @@ int refresh_all(FactHandle* h, hipStream_t s) {
 int adam_bucket(FactHandle* h, int b, hipStream_t s) {
   const Bucket& k = h->buckets[b];
   const AdamArgs& a = h->adam;
+  if (h->fuse_adam_cast)
+    return launch_adam_fused(h->adam_blocks + k.blk_first, k.blk_n, h->params, h->adam_m, h->adam_v, h->grads,
+                             a.lr_t, a.b1, a.b2, a.eps, a.gscale, s);
   CHK(launch_adam(h->params + k.off, h->adam_m + k.off, h->adam_v + k.off, h->grads + k.off, k.cnt, a.lr_t,
                   a.b1, a.b2, a.eps, a.gscale, s));
   return refresh_bucket(h, b, s);
@@ -814,6 +858,7 @@ int fact_destroy(FactHandle* h) {
   (void)hipFree(h->shadow);
   (void)hipFree(h->work);
   (void)hipFree(h->cast_table);
+  (void)hipFree(h->adam_blocks);
   for (hipEvent_t e : h->ev) (void)hipEventDestroy(e);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->opt) (void)hipStreamDestroy(h->opt);
@@ -856,6 +901,10 @@ int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* com
 
 int fact_set_option(FactHandle* h, const char* key, int value) {
   if (!h || !key) return fail(-1, "null argument");
+  if (!strcmp(key, "fuse_adam_cast")) {
+    h->fuse_adam_cast = value;
+    return 0;
+  }
   if (!strcmp(key, "wgrad_tr")) {
     h->wgrad_tr = value;
     return 0;
@@ -963,6 +1012,11 @@ int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps,
   h->step += 1;
   const double t = (double)h->step;
   const double lr_t = (double)lr * std::sqrt(1.0 - std::pow((double)beta2, t)) / (1.0 - std::pow((double)beta1, t));
+  if (h->fuse_adam_cast && !h->buckets.empty()) {
+    const Bucket& last = h->buckets.back();
+    return launch_adam_fused(h->adam_blocks, last.blk_first + last.blk_n, h->params, h->adam_m, h->adam_v,
+                             h->grads, (float)lr_t, beta1, beta2, eps, gscale, s);
+  }
   CHK(launch_adam(h->params, h->adam_m, h->adam_v, h->grads, h->arena_floats, (float)lr_t, beta1, beta2,
                   eps, gscale, s));
   return refresh_all(h, s);

@@ -41,6 +41,23 @@ int launch_mse_loss(const float* pred, const float* target, float* loss_sum, bf1
 int launch_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, float b1, float b2,
                 float eps, float gscale, hipStream_t s);
 
+// Keras Adam FUSED with the bf16 weight-shadow refresh: one workgroup per AdamBlock.  A dense block is
+// one 64x64 tile of a Dense kernel [R][C] at arena offset `off`: p/m/v/g are updated in place (g zeroed)
+// and the new weights are written as bf16 to s [R][lds] and, through an LDS transpose, to t [C][ldt] -
+// the master weights are not re-read by a separate cast pass.  A flat block (R == 0) is `C` floats
+// (multiple of 4, <= 4096) of non-Dense parameters (biases, LayerNorm, position tables, arena padding).
+// `blocks` lives in device memory; every block is independent.
+struct AdamBlock {
+  unsigned long long off;  // float offset into the four arenas (dense: of element [0][0] of the tensor)
+  bf16_t* s;
+  bf16_t* t;
+  int R, C, lds, ldt;
+  int r0, c0;
+  int pad[4];
+};
+int launch_adam_fused(const AdamBlock* blocks, int nblocks, float* p, float* m, float* v, float* g,
+                      float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s);
+
 // f32 [R][C] -> bf16 dst [R][ldd] and bf16 dstT [C][ldt] (either may be null)
 int launch_cast_transpose(const float* src, int R, int C, bf16_t* dst, int ldd, bf16_t* dstT, int ldt,
                           hipStream_t s);

@@ -275,6 +275,93 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, float
   }
 }
 
+DEVINL void adam1(float& p, float& m, float& v, float g, float lr_t, float b1, float b2, float eps) {
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  p -= lr_t * m / (sqrtf(v) + eps);
+}
+
+__global__ __launch_bounds__(256) void adam_fused_kernel(const AdamBlock* __restrict__ blocks,
+                                                         float* __restrict__ P, float* __restrict__ Mm,
+                                                         float* __restrict__ V, float* __restrict__ G,
+                                                         float lr_t, float b1, float b2, float eps,
+                                                         float gscale) {
+  __shared__ float tile[64][65];
+  const AdamBlock d = blocks[blockIdx.x];
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (d.R == 0) {  // flat segment
+    for (int i = threadIdx.x * 4; i < d.C; i += 1024) {
+      const size_t o = d.off + i;
+      float4 gv = *reinterpret_cast<const float4*>(G + o), mv = *reinterpret_cast<const float4*>(Mm + o);
+      float4 vv = *reinterpret_cast<const float4*>(V + o), pv = *reinterpret_cast<const float4*>(P + o);
+      adam1(pv.x, mv.x, vv.x, gv.x * gscale, lr_t, b1, b2, eps);
+      adam1(pv.y, mv.y, vv.y, gv.y * gscale, lr_t, b1, b2, eps);
+      adam1(pv.z, mv.z, vv.z, gv.z * gscale, lr_t, b1, b2, eps);
+      adam1(pv.w, mv.w, vv.w, gv.w * gscale, lr_t, b1, b2, eps);
+      *reinterpret_cast<float4*>(P + o) = pv;
+      *reinterpret_cast<float4*>(Mm + o) = mv;
+      *reinterpret_cast<float4*>(V + o) = vv;
+      *reinterpret_cast<float4*>(G + o) = z;
+    }
+    return;
+  }
+  const int cx = (threadIdx.x & 15) * 4, ry = threadIdx.x >> 4;  // 16 column-quads x 16 rows
+  const bool vec_ok = ((d.C & 3) == 0);
+#pragma unroll
+  for (int rr = ry; rr < 64; rr += 16) {
+    const int r = d.r0 + rr, c = d.c0 + cx;
+    float w[4] = {0.f, 0.f, 0.f, 0.f};
+    if (r < d.R) {
+      const size_t o = d.off + (size_t)r * d.C + c;
+      if (vec_ok && c + 3 < d.C) {
+        float4 gv = *reinterpret_cast<const float4*>(G + o), mv = *reinterpret_cast<const float4*>(Mm + o);
+        float4 vv = *reinterpret_cast<const float4*>(V + o), pv = *reinterpret_cast<const float4*>(P + o);
+        adam1(pv.x, mv.x, vv.x, gv.x * gscale, lr_t, b1, b2, eps);
+        adam1(pv.y, mv.y, vv.y, gv.y * gscale, lr_t, b1, b2, eps);
+        adam1(pv.z, mv.z, vv.z, gv.z * gscale, lr_t, b1, b2, eps);
+        adam1(pv.w, mv.w, vv.w, gv.w * gscale, lr_t, b1, b2, eps);
+        *reinterpret_cast<float4*>(P + o) = pv;
+        *reinterpret_cast<float4*>(Mm + o) = mv;
+        *reinterpret_cast<float4*>(V + o) = vv;
+        *reinterpret_cast<float4*>(G + o) = z;
+        w[0] = pv.x; w[1] = pv.y; w[2] = pv.z; w[3] = pv.w;
+        bf16x4 o16 = {(bf16_t)w[0], (bf16_t)w[1], (bf16_t)w[2], (bf16_t)w[3]};
+        *reinterpret_cast<bf16x4*>(d.s + (size_t)r * d.lds + c) = o16;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < d.C) {
+            float pv = P[o + j], mv = Mm[o + j], vv = V[o + j];
+            adam1(pv, mv, vv, G[o + j] * gscale, lr_t, b1, b2, eps);
+            P[o + j] = pv; Mm[o + j] = mv; V[o + j] = vv; G[o + j] = 0.f;
+            w[j] = pv;
+            d.s[(size_t)r * d.lds + c + j] = (bf16_t)pv;
+          }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile[rr][cx + j] = w[j];
+  }
+  __syncthreads();
+  // transposed shadow: thread -> column cc, 4 consecutive rows
+  const int rq = (threadIdx.x & 15) * 4, cy = threadIdx.x >> 4;
+#pragma unroll
+  for (int cc = cy; cc < 64; cc += 16) {
+    const int c = d.c0 + cc, r = d.r0 + rq;
+    if (c < d.C) {
+      if (r + 3 < d.R) {
+        bf16x4 o = {(bf16_t)tile[rq][cc], (bf16_t)tile[rq + 1][cc], (bf16_t)tile[rq + 2][cc],
+                    (bf16_t)tile[rq + 3][cc]};
+        *reinterpret_cast<bf16x4*>(d.t + (size_t)c * d.ldt + r) = o;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r + j < d.R) d.t[(size_t)c * d.ldt + r + j] = (bf16_t)tile[rq + j][cc];
+      }
+    }
+  }
+}
+
 // 64x64 tile cast/transpose through LDS
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const T* __restrict__ src, int lds_,
@@ -539,6 +626,14 @@ int launch_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, fl
   const size_t n4 = n >> 2;
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, 256, 8192)), dim3(256), 0, s, (float4*)p,
                      (float4*)m, (float4*)v, (float4*)g, n4, lr_t, b1, b2, eps, gscale);
+  return 0;
+}
+
+int launch_adam_fused(const AdamBlock* blocks, int nblocks, float* p, float* m, float* v, float* g,
+                      float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s) {
+  if (nblocks <= 0) return 0;
+  hipLaunchKernelGGL(adam_fused_kernel, dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, lr_t, b1, b2, eps,
+                     gscale);
   return 0;
 }
 

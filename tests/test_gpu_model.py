@@ -343,6 +343,37 @@ def test_fused_optimizer_in_backward_matches_separate_step():
     assert torch.allclose(finals[0][1], finals[1][1], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("fused_step", [False, True])
+def test_adam_fused_with_shadow_refresh_matches_two_kernel_path(fused_step):
+    """The fused Adam + bf16-shadow kernel (one pass over p/m/v/g that also writes both weight shadows)
+    against the two-kernel path (flat Adam, then cast/transpose): same per-element arithmetic (up to fma
+    contraction and the atomic order of the bias/LayerNorm gradient sums), so master weights, both
+    moments and the next forward (which reads the shadows) agree to fp32 round-off - including the
+    ragged 225 / 35-wide embedding and head kernels.  Tolerance: rtol 1e-5 / atol 1e-7 on the fp32
+    state, 2e-3 relative on the bf16-computed forward."""
+    cfg = O.TINY_CFG
+    batches = [gpu_batch(O.synthetic_batch(cfg, 4, 8, seed=s)) for s in (1, 2, 3)]
+    finals = []
+    for fuse_cast in (0, 1):
+        torch.manual_seed(0)
+        model = model_builder.build(make_config(cfg), True)
+        model.build(4, 225, 35)
+        model.set_option("fuse_adam_cast", fuse_cast)
+        tr = SingleTaskTrainer(batches, "target", model, optimizer=Adam(1e-3), fuse_optimizer=fused_step)
+        it = iter(batches)
+        for _ in range(3):
+            tr.train_step(it)
+        inp = {k: v for k, v in batches[0].items() if k != "target"}
+        out = model(inp).clone()
+        torch.cuda.synchronize()
+        st = model.state_dict()
+        finals.append((out.cpu(), {k: v.clone().cpu() for k, v in st.items() if torch.is_tensor(v)}))
+    assert (finals[0][0] - finals[1][0]).norm() / finals[0][0].norm() < 2e-3
+    for k in finals[0][1]:
+        assert torch.allclose(finals[0][1][k], finals[1][1][k], rtol=1e-5, atol=1e-7), k
+    assert float(finals[1][1]["grads"].abs().max()) == 0.0
+
+
 def test_ragged_lengths_second_step_grads():
     """Sequence lengths that are not multiples of the 32-token attention tile (40 / 72 / 112) and a
     SECOND backward pass through the shared scratch buffers: padding rows of the per-head dO scratch
