@@ -533,6 +533,141 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_nt_ring_kernel(const GemmPar
 }
 
 // ------------------------------------------------------------------------------------------
+// big-tile NT: (32*MR) x 256 block tile, 8 waves = 2 (M) x 4 (N), each wave a (16*MR) x 64 sub-tile
+// (MR x 4 MFMA tiles, MR = 8 or 9), 32-deep K stages in a 4-deep LDS ring with counted vmcnt.
+// Why: the 128x128 / 4-wave kernel reads 8 fragments from LDS per 16 MFMAs and stages 64 FLOP per
+// LDS-DMA byte; here a wave reads MR+4 fragments per 4*MR MFMAs (0.36 vs 0.5 per MFMA) and a stage
+// carries 2x the FLOPs per DMA byte, so the LDS pipe and the DMA issue slots stop being the limit.
+// One workgroup per CU (136 KiB of LDS): the tile height is picked so that the grid is <= 256
+// workgroups (M = 5760 -> MR = 9: 20 x 12 tiles of 288 x 256 for the FFN1 shape).
+// Stage image: [rows][32 k] 64-byte rows, chunk swizzle ring_g (see the ring kernel above).
+// ------------------------------------------------------------------------------------------
+template <int EPI, int MR>
+__global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const GemmParams p) {
+  constexpr int BMB = 32 * MR, BNB = 256;
+  constexpr int NSTAGE = 4, DIST = NSTAGE - 1;
+  constexpr int A_PIECES = BMB * 64 / 1024, B_PIECES = BNB * 64 / 1024;  // 1 KiB = 16 rows x 64 B
+  constexpr int A_BYTES = A_PIECES * 1024, STAGE_BYTES = A_BYTES + B_PIECES * 1024;
+  constexpr int NPIECE = A_PIECES + B_PIECES;  // 34 (MR = 9) or 32 (MR = 8)
+  constexpr int LPS_LO = NPIECE / 8, EXTRA = NPIECE % 8;  // waves < EXTRA issue one more piece
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_big[];
+  unsigned char* smem = smem_big;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-role branches stay uniform
+  const int wm = wave >> 2, wn = wave & 3;
+
+  const int tn = (p.N + BNB - 1) / BNB, tm = (p.M + BMB - 1) / BMB;
+  int m0, n0;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    // bands of 4 m-tiles, m fastest: the ~32 tiles of an XCD form a near-square patch
+    const int band = 4, per = band * tn;
+    const int b = id / per, w = id - b * per;
+    const int hb = min(band, tm - b * band);
+    m0 = (b * band + w % hb) * BMB;
+    n0 = (w / hb) * BNB;
+  }
+  const int nk = p.K / 32;
+
+  // DMA pieces of this wave: piece index q in [0, NPIECE): q < A_PIECES -> A rows q*16.., else B rows
+  const int npc = LPS_LO + (wave < EXTRA ? 1 : 0);
+  const int lrow = lane >> 2;                                  // row inside the 16-row piece
+  const int lchunk = (lane & 3) ^ ring_g(lrow);                // logical 16-byte chunk this lane fetches
+  const bf16_t* src[LPS_LO + 1];
+  int dst[LPS_LO + 1];
+#pragma unroll
+  for (int i = 0; i < LPS_LO + 1; ++i) {
+    const int q = (i < LPS_LO) ? wave * LPS_LO + i : 8 * LPS_LO + wave;  // extras: pieces 8*LPS_LO..
+    const int qq = min(q, NPIECE - 1);
+    if (qq < A_PIECES) {
+      src[i] = p.A + (size_t)min(m0 + qq * 16 + lrow, p.M - 1) * p.lda + lchunk * 8;
+      dst[i] = qq * 1024;
+    } else {
+      src[i] = p.B + (size_t)min(n0 + (qq - A_PIECES) * 16 + lrow, p.N - 1) * p.ldb + lchunk * 8;
+      dst[i] = A_BYTES + (qq - A_PIECES) * 1024;
+    }
+  }
+  auto stage = [&](int kt) {
+    unsigned char* base = smem + (kt % NSTAGE) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < LPS_LO; ++i) glds16(src[i] + kt * 32, base + dst[i]);
+    if (EXTRA && wave < EXTRA) glds16(src[LPS_LO] + kt * 32, base + dst[LPS_LO]);
+  };
+  auto wait_for = [&](int stages_after) {  // wave-uniform: this wave has npc loads per stage
+    if (EXTRA && wave < EXTRA) wait_stages<LPS_LO + 1>(stages_after);
+    else wait_stages<LPS_LO>(stages_after);
+  };
+
+  f32x4 acc[MR][4];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int s2 = 0; s2 < DIST; ++s2)
+    if (s2 < nk) stage(s2);
+  wait_for(min(DIST - 1, nk - 1));
+  __builtin_amdgcn_s_barrier();  // stage 0 landed
+
+  // Two wave groups (wm = 0 / 1; each SIMD holds one wave of each) run half a step apart: while one
+  // group issues its DMA pieces and reads its MR + 4 fragments from LDS, the other multiplies the
+  // fragments it read in the previous phase - the LDS pipe and the MFMA pipe of a SIMD are busy at
+  // the same time instead of taking turns.  Two barriers per K step keep the phases aligned:
+  //   phase 2k   : group 0 stages k+3 and reads k      | group 1 multiplies k-1
+  //   phase 2k+1 : group 0 multiplies k                | group 1 stages k+3 and reads k
+  // Both groups run the same loop body; group 1 simply enters it one barrier later.  Every wave
+  // retires its own pieces of stage k+1 (counted vmcnt) before the barrier that ends phase 2k+1 -
+  // after its multiply for group 0, after its reads for group 1 - and its fragment reads (lgkmcnt)
+  // before the barrier that ends its read phase, so a ring slot is only re-armed after both groups
+  // are done with it.
+  bf16x8 af[MR], bfr[4];
+  auto read_frags = [&](int kt) {
+    if (kt + DIST < nk) stage(kt + DIST);
+    const unsigned char* As = smem + (kt % NSTAGE) * STAGE_BYTES;
+    const unsigned char* Bs = As + A_BYTES;
+    const int chunk = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = ring_frag<32>(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
+#pragma unroll
+    for (int i = 0; i < MR; ++i) af[i] = ring_frag<32>(As, wm * (16 * MR) + i * 16 + (lane & 15), chunk);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  auto multiply = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = kSwap<EPI> ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one phase behind group 0
+  for (int kt = 0; kt < nk; ++kt) {
+    read_frags(kt);
+    if (wm == 1 && kt + 1 < nk) wait_for(min(DIST - 1, nk - 2 - kt));
+    __builtin_amdgcn_s_barrier();
+    multiply();
+    if (wm == 0 && kt + 1 < nk) wait_for(min(DIST - 1, nk - 2 - kt));
+    __builtin_amdgcn_s_barrier();
+  }
+  if (wm == 0) __builtin_amdgcn_s_barrier();
+  EpiParams ep = p.ep;
+  ep.z = 0;
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      static_assert(kSwap<EPI>, "big-tile kernel: swapped MFMA roles only");
+      const int row = m0 + wm * (16 * MR) + i * 16 + (lane & 15);
+      const int col0 = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      epilogue_store<EPI>(ep, p.M, p.N, row, col0, acc[i][j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // fast TN: A[k*lda + m], B[k*ldb + n]; requires K % 64 == 0
 // ------------------------------------------------------------------------------------------
 template <int EPI>
@@ -932,6 +1067,45 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
   int variant = g_nt_variant;
   if (p.splitk > 1) variant = 1;
   else if (variant == 0) variant = 1;  // measured: the 2-stage 128x128 kernel wins at every FACT shape
+  if constexpr (EPI != EPI_ATOMIC_F32) {
+    // Big-tile kernel (one 288x256 or 256x256 workgroup per CU): taken when the whole GEMM is ONE round
+    // of at least ~60 % of the CUs - e.g. M = 5760, N = 3072 -> 20 x 12 = 240 tiles of 288 x 256.
+    // With more tiles than CUs its second round runs mostly empty, with far fewer the 128x128 kernel's
+    // finer tiling wins (measured, tools/gemm_bench.py).
+    const int tnb = (p.N + 255) / 256;
+    const int t9 = tnb * ((p.M + 287) / 288), t8 = tnb * ((p.M + 255) / 256);
+    int mr = 0;
+    if (variant == 6) mr = 9;
+    else if (variant == 7) mr = 8;
+    else if (variant == 1 && g_nt_variant == 0 && p.splitk == 1) {
+      const bool ok9 = t9 >= 160 && t9 <= 256, ok8 = t8 >= 160 && t8 <= 256;
+      if (ok9 && ok8) mr = (t8 > t9) ? 8 : 9;
+      else if (ok9) mr = 9;
+      else if (ok8) mr = 8;
+    }
+    if (mr == 9) {
+      constexpr int LDSB = 4 * (288 + 256) * 64;
+      static bool once = false;
+      if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<EPI, 9>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        once = true;
+      }
+      hipLaunchKernelGGL((gemm_nt_big_kernel<EPI, 9>), dim3(t9), dim3(512), LDSB, s, p);
+      return 0;
+    }
+    if (mr == 8) {
+      constexpr int LDSB = 4 * (256 + 256) * 64;
+      static bool once = false;
+      if (!once) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<EPI, 8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+        once = true;
+      }
+      hipLaunchKernelGGL((gemm_nt_big_kernel<EPI, 8>), dim3(t8), dim3(512), LDSB, s, p);
+      return 0;
+    }
+  }
   if (variant == 4)
     hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, 4, 3, 64>), dim3(tiles256), dim3(512), 0, s, p);
   else if (variant == 3)

@@ -104,6 +104,29 @@ def gemm_path(request):
     L.lib().fact_debug_force_generic_gemm(0)
 
 
+@pytest.fixture(params=[0, 1, 6, 7], ids=["auto", "tile128", "big288", "big256"])
+def nt_variant(request):
+    """NT kernel choice: the engine's automatic pick, the 128x128 kernel, and both big-tile kernels
+    (288x256 / 256x256, staggered wave groups) forced regardless of the tile-count heuristic."""
+    L.lib().fact_debug_gemm_nt_variant(request.param)
+    yield request.param
+    L.lib().fact_debug_gemm_nt_variant(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(5760, 3072, 800), (300, 500, 96), (288, 256, 32), (577, 260, 160),
+                                   (3840, 2400, 800), (64, 72, 64)])
+def test_gemm_nt_variants(nt_variant, M, N, K):
+    """Every NT kernel on full, ragged (M, N not multiples of the tile) and single-K-step shapes."""
+    g = torch.Generator(device=DEV).manual_seed(11)
+    A = _bf(torch.randn(M, K, device=DEV, generator=g))
+    B = _bf(torch.randn(N, K, device=DEV, generator=g))
+    out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _gemm_nt(L.EPI_BF16, A, B, M, N, K, out)
+    ref = A.float() @ B.float().t()
+    _close(out, ref, 1e-2, 1e-2 * math.sqrt(K), "gemm_nt")
+    assert _rel_err(out, ref) < 4e-3
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (200, 136, 72), (5760, 2400, 800),
                                    (1920, 800, 3072), (333, 225, 800), (64, 800, 256), (130, 132, 96)])
 def test_gemm_nt_bf16(gemm_path, M, N, K):
@@ -117,7 +140,7 @@ def test_gemm_nt_bf16(gemm_path, M, N, K):
     assert _rel_err(out, ref) < 4e-3
 
 
-def test_gemm_nt_epilogues():
+def test_gemm_nt_epilogues(nt_variant):
     M, N, K, seq = 480, 800, 256, 120
     g = torch.Generator(device=DEV).manual_seed(2)
     A = _bf(torch.randn(M, K, device=DEV, generator=g))
