@@ -37,26 +37,29 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-phase timing to stderr")
     ap.add_argument("--side-stream", type=int, default=1, help="0 = single-stream engine (A/B knob)")
+    ap.add_argument("--fuse-optimizer", type=int, default=0, help="1 = per-bucket Adam inside backward (A/B knob)")
     return ap.parse_args()
 
 
 def gemm_roofline(device):
-    """Dominant kernel: gemm_nt_kernel (bf16 MFMA). Algorithmic FLOPs per launch at the cross-modal
-    FFN1 shape M=5760 (16*360 tokens), N=3072, K=800: 2*M*N*K = 28.31 GFLOP; timed with HIP events
-    on the stream the kernel is launched on."""
+    """Dominant kernel: the bf16 MFMA NT GEMM with the bias+GELU epilogue (gemm_nt_big_kernel<BIAS_GELU>,
+    288x256 tiles) at the cross-modal FFN1 shape M=5760 (16*360 tokens), N=3072, K=800, operands at the
+    engine's 832-element row pitch.  Algorithmic FLOPs per launch 2*M*N*K = 28.31 GFLOP; timed with HIP
+    events on the stream the kernel is launched on."""
     from mint_amd import _lib as L
     lib = L.lib()
     M, N, K = BATCH_PER_GPU * 360, 3072, 800
     g = torch.Generator(device=device).manual_seed(0)
-    A = torch.randn(M, K, device=device, generator=g).to(torch.bfloat16)
-    B = (torch.randn(N, K, device=device, generator=g) * 0.05).to(torch.bfloat16)
+    LD = 832  # bf16 row pitch used by the engine for 800-wide activations / weight shadows
+    A = torch.randn(M, LD, device=device, generator=g).to(torch.bfloat16)
+    B = (torch.randn(N, LD, device=device, generator=g) * 0.05).to(torch.bfloat16)
     bias = torch.zeros(N, device=device)
     pre = torch.empty(M, N, device=device, dtype=torch.bfloat16)
     act = torch.empty(M, N, device=device, dtype=torch.bfloat16)
     stream = torch.cuda.current_stream()
 
     def launch():
-        L.check(lib.fact_op_gemm_nt(L.EPI_BIAS_GELU, L.ptr(A), K, L.ptr(B), K, M, N, K, L.ptr(pre), N,
+        L.check(lib.fact_op_gemm_nt(L.EPI_BIAS_GELU, L.ptr(A), LD, L.ptr(B), LD, M, N, K, L.ptr(pre), N,
                                     L.ptr(act), N, L.ptr(bias), None, 0, None, 0, None, 0,
                                     L.cur_stream()))
     for _ in range(5):
@@ -76,7 +79,7 @@ def gemm_roofline(device):
         traffic = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))["traffic_bytes"]
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "gemm_nt_fast_kernel<EPI_BIAS_GELU> M5760 N3072 K800",
+    return {"bound": "mfma", "kernel": "gemm_nt_big_kernel<EPI_BIAS_GELU, 9> (288x256 tiles) M5760 N3072 K800",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
             "flop_per_launch": flops, "traffic": traffic}
@@ -161,7 +164,7 @@ def main():
         def __next__(self):
             return batch
 
-    trainer = SingleTaskTrainer(Repeat(), "target", model, optimizer=opt)
+    trainer = SingleTaskTrainer(Repeat(), "target", model, optimizer=opt, fuse_optimizer=bool(args.fuse_optimizer))
     it = iter(Repeat())
 
     def sync():
