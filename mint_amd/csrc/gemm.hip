@@ -1068,20 +1068,20 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
   if (p.splitk > 1) variant = 1;
   else if (variant == 0) variant = 1;  // measured: the 2-stage 128x128 kernel wins at every FACT shape
   if constexpr (EPI != EPI_ATOMIC_F32) {
-    // Big-tile kernel (one 288x256 or 256x256 workgroup per CU): taken when the whole GEMM is ONE round
-    // of at least ~60 % of the CUs - e.g. M = 5760, N = 3072 -> 20 x 12 = 240 tiles of 288 x 256.
-    // With more tiles than CUs its second round runs mostly empty, with far fewer the 128x128 kernel's
-    // finer tiling wins (measured, tools/gemm_bench.py).
+    // Big-tile kernel (one 288x256 or 256x256 workgroup per CU): taken when its rounds of 256
+    // workgroups are well filled, counting tile padding: useful outputs / (rounds * 256 * tile area)
+    // >= 0.6 - e.g. M = 5760, N = 3072 -> 20 x 12 = 240 tiles of 288 x 256 (0.94).  A GEMM that leaves a
+    // round mostly empty (276 tiles) or whose N is far below a tile (N = 800) stays on the 128x128 kernel.
     const int tnb = (p.N + 255) / 256;
     const int t9 = tnb * ((p.M + 287) / 288), t8 = tnb * ((p.M + 255) / 256);
     int mr = 0;
     if (variant == 6) mr = 9;
     else if (variant == 7) mr = 8;
     else if (variant == 1 && g_nt_variant == 0 && p.splitk == 1) {
-      const bool ok9 = t9 >= 160 && t9 <= 256, ok8 = t8 >= 160 && t8 <= 256;
-      if (ok9 && ok8) mr = (t8 > t9) ? 8 : 9;
-      else if (ok9) mr = 9;
-      else if (ok8) mr = 8;
+      const double useful = (double)p.M * p.N;
+      const double e9 = useful / ((double)((t9 + 255) / 256) * 256 * 288 * 256);
+      const double e8 = useful / ((double)((t8 + 255) / 256) * 256 * 256 * 256);
+      if (e9 >= 0.6 || e8 >= 0.6) mr = (e8 > e9) ? 8 : 9;
     }
     if (mr == 9) {
       constexpr int LDSB = 4 * (288 + 256) * 64;
