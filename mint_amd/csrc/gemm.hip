@@ -335,6 +335,74 @@ DEVINL void compute_tile(const unsigned char* As, const unsigned char* Bs, f32x4
   }
 }
 
+// Full-line epilogue of the 128x128 NT kernel (same idea as in the big-tile kernel): each wave re-shapes
+// its 64x64 accumulator tile in a private XOR-swizzled piece of the idle stage buffers and stores 16 bytes
+// per lane, so a wave store covers whole 128-byte (bf16) / 256-byte (fp32) row segments instead of
+// 16 rows x 32/64 bytes; the fp32 residual is read in the same pattern.  Returns false when the output
+// geometry is not 16-byte granular (the caller then takes the direct path).
+template <int EPI>
+DEVINL bool staged_epilogue_128(const GemmParams& p, f32x4 (&acc)[4][4], unsigned char* smem, int m0, int n0,
+                                int wave, int wm, int wn, int lane) {
+  const EpiParams& ep = p.ep;
+  const int wrow0 = m0 + wm * 64, wcol0 = n0 + wn * 64;
+  if constexpr (EPI == EPI_BF16) {
+    if ((p.N & 7) || (ep.ldo0 & 7)) return false;
+    unsigned char* stg = smem + wave * 8192;  // [64 rows][128 B]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int lr = i * 16 + (lane & 15), lc = j * 16 + (lane >> 4) * 4;
+        const f32x4 v = acc[i][j];
+        const bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(stg + lr * 128 + (((lc >> 3) ^ (lr & 7)) << 4) + (lc & 7) * 2) = o;
+      }
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) {
+      const int lr = rr * 8 + (lane >> 3), ch = lane & 7;
+      const int row = wrow0 + lr, col = wcol0 + ch * 8;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(stg + lr * 128 + ((ch ^ (lr & 7)) << 4));
+      if (row < p.M && col < p.N) *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v;
+    }
+    return true;
+  } else if constexpr (EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_POS || EPI == EPI_F32_BIAS_RESID) {
+    if ((p.N & 3) || (ep.ldo0 & 3) || (EPI == EPI_F32_BIAS_RESID && (ep.ldr & 3))) return false;
+    unsigned char* stg = smem + wave * 16384;  // [64 rows][256 B], 16 float4 chunks per row
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int lr = i * 16 + (lane & 15), cq = j * 4 + (lane >> 4);  // float4 chunk index in the row
+        const f32x4 v = acc[i][j];
+        *reinterpret_cast<float4*>(stg + lr * 256 + ((cq ^ (lr & 15)) << 4)) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int lr = rr * 4 + (lane >> 4), cq = lane & 15;
+      const int row = wrow0 + lr, col = wcol0 + cq * 4;
+      float4 v = *reinterpret_cast<const float4*>(stg + lr * 256 + ((cq ^ (lr & 15)) << 4));
+      if (row < p.M && col < p.N) {
+        if (ep.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(ep.bias + col);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if constexpr (EPI == EPI_F32_BIAS_POS) {
+          const float4 e = *reinterpret_cast<const float4*>(ep.pos + (size_t)(row % ep.seq) * p.N + col);
+          v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        }
+        if constexpr (EPI == EPI_F32_BIAS_RESID) {
+          const float4 e = *reinterpret_cast<const float4*>(ep.resid + (size_t)row * ep.ldr + col);
+          v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+        }
+        *reinterpret_cast<float4*>((float*)ep.out0 + (size_t)row * ep.ldo0 + col) = v;
+      }
+    }
+    return true;
+  } else {
+    return false;
+  }
+}
+
 DEVINL void zero_acc(f32x4 (&acc)[4][4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -403,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast_kernel(const GemmParams p
     __syncthreads();
     buf ^= 1;
   }
+  if (p.splitk == 1 && staged_epilogue_128<EPI>(p, acc, smem, m0, n0, wave, wm, wn, lane)) return;
   run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, bc.z);
 }
 
@@ -656,11 +725,88 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const GemmParams p)
   if (wm == 0) __builtin_amdgcn_s_barrier();
   EpiParams ep = p.ep;
   ep.z = 0;
+  static_assert(kSwap<EPI>, "big-tile kernel: swapped MFMA roles only");
+  // bf16 outputs leave through LDS: in the MFMA layout a lane owns 4 consecutive columns (8 bytes) and a
+  // wave store covers 16 rows x 32 bytes; with one workgroup per CU nothing hides that 35-70 MB burst.
+  // Each wave re-shapes its 144 x 64 sub-tile in a private, XOR-swizzled piece of the (now idle) stage
+  // ring, 48 / 64 rows at a time, and stores 16 bytes per lane = whole 128-byte row segments
+  // (FFN1 plain epilogue 39.4 -> 32.6 us).
+  constexpr bool kStaged = (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD);
+  if constexpr (kStaged) {
+    constexpr int NOUT = (EPI == EPI_BIAS_GELU) ? 2 : 1;
+    const bool aligned = !(p.N & 7) && !(ep.ldo0 & 7) && (NOUT == 1 || !(ep.ldo1 & 7)) &&
+                         (EPI != EPI_GELU_BWD || !(ep.ldp & 7));
+    if (aligned) {
+      constexpr int CH = (MR % 3 == 0) ? 3 : 4;  // MFMA row-blocks per pass: 9 = 3 x 3, 8 = 2 x 4
+      constexpr int REG = CH * 16 * 128;          // bytes of one staged output per wave
+      unsigned char* stg = smem + wave * (NOUT * REG);
+      const int wrow0 = m0 + wm * (16 * MR), wcol0 = n0 + wn * 64;
+#pragma unroll
+      for (int c = 0; c < MR / CH; ++c) {
+        if constexpr (EPI == EPI_GELU_BWD) {
+          // the saved pre-activation comes in the same way it goes out: whole 128-byte row segments
+          // into the staging image, then each lane picks its 4 values at the offset it will overwrite
+#pragma unroll
+          for (int rr = 0; rr < CH * 2; ++rr) {
+            const int lr = rr * 8 + (lane >> 3), ch = lane & 7;
+            const int row = min(wrow0 + c * CH * 16 + lr, p.M - 1), col = wcol0 + ch * 8;
+            bf16x8 pv = {};
+            if (col < p.N) pv = *reinterpret_cast<const bf16x8*>(ep.pre + (size_t)row * ep.ldp + col);
+            *reinterpret_cast<bf16x8*>(stg + lr * 128 + ((ch ^ (lr & 7)) << 4)) = pv;
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii) {
+          const int i = c * CH + ii;
+          const int lr = ii * 16 + (lane & 15);  // row inside this pass
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int lc = j * 16 + (lane >> 4) * 4;  // column inside the 64-wide wave tile
+            const int col = wcol0 + lc;
+            const f32x4 v = acc[i][j];
+            bf16x4 o0, o1;
+            if constexpr (EPI == EPI_BF16) {
+              o0 = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            } else if constexpr (EPI == EPI_BIAS_GELU) {
+              float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (col < p.N) b = *reinterpret_cast<const float4*>(ep.bias + col);
+              const float x0 = v[0] + b.x, x1 = v[1] + b.y, x2 = v[2] + b.z, x3 = v[3] + b.w;
+              o0 = bf16x4{(bf16_t)x0, (bf16_t)x1, (bf16_t)x2, (bf16_t)x3};
+              o1 = bf16x4{(bf16_t)gelu_tanh(x0), (bf16_t)gelu_tanh(x1), (bf16_t)gelu_tanh(x2), (bf16_t)gelu_tanh(x3)};
+            } else {  // EPI_GELU_BWD
+              const bf16x4 pv = *reinterpret_cast<const bf16x4*>(
+                  stg + lr * 128 + ((((lc >> 3) ^ (lr & 7))) << 4) + (lc & 7) * 2);
+              o0 = bf16x4{(bf16_t)(v[0] * gelu_tanh_grad((float)pv[0])), (bf16_t)(v[1] * gelu_tanh_grad((float)pv[1])),
+                          (bf16_t)(v[2] * gelu_tanh_grad((float)pv[2])), (bf16_t)(v[3] * gelu_tanh_grad((float)pv[3]))};
+            }
+            // 16-byte chunk (lc / 8) of row lr sits at chunk position (lc / 8) ^ (lr & 7)
+            const int off = lr * 128 + ((((lc >> 3) ^ (lr & 7))) << 4) + (lc & 7) * 2;
+            *reinterpret_cast<bf16x4*>(stg + off) = o0;
+            if constexpr (NOUT == 2) *reinterpret_cast<bf16x4*>(stg + REG + off) = o1;
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < CH * 2; ++rr) {
+          const int lr = rr * 8 + (lane >> 3), ch = lane & 7;
+          const int row = wrow0 + c * CH * 16 + lr, col = wcol0 + ch * 8;
+          const int off = lr * 128 + ((ch ^ (lr & 7)) << 4);
+          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + off);
+          if (row < p.M && col < p.N) {
+            *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v0;
+            if constexpr (NOUT == 2) {
+              const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + REG + off);
+              *reinterpret_cast<bf16x8*>((bf16_t*)ep.out1 + (size_t)row * ep.ldo1 + col) = v1;
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      static_assert(kSwap<EPI>, "big-tile kernel: swapped MFMA roles only");
       const int row = m0 + wm * (16 * MR) + i * 16 + (lane & 15);
       const int col0 = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
       epilogue_store<EPI>(ep, p.M, p.N, row, col0, acc[i][j]);
