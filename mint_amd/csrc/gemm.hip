@@ -365,8 +365,14 @@ DEVINL bool staged_epilogue_128(const GemmParams& p, f32x4 (&acc)[4][4], unsigne
       if (row < p.M && col < p.N) *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v;
     }
     return true;
-  } else if constexpr (EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_POS || EPI == EPI_F32_BIAS_RESID) {
+  } else if constexpr (EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_POS || EPI == EPI_F32_BIAS_RESID ||
+                       EPI == EPI_F32_SLAB) {
     if ((p.N & 3) || (ep.ldo0 & 3) || (EPI == EPI_F32_BIAS_RESID && (ep.ldr & 3))) return false;
+    float* outp = (float*)ep.out0;
+    if constexpr (EPI == EPI_F32_SLAB) {  // split-K partial: slab z of the caller's slab buffer
+      if (ep.slab_stride & 3) return false;
+      outp += (size_t)ep.z * ep.slab_stride;
+    }
     unsigned char* stg = smem + wave * 16384;  // [64 rows][256 B], 16 float4 chunks per row
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -382,7 +388,7 @@ DEVINL bool staged_epilogue_128(const GemmParams& p, f32x4 (&acc)[4][4], unsigne
       const int row = wrow0 + lr, col = wcol0 + cq * 4;
       float4 v = *reinterpret_cast<const float4*>(stg + lr * 256 + ((cq ^ (lr & 15)) << 4));
       if (row < p.M && col < p.N) {
-        if (ep.bias) {
+        if (EPI != EPI_F32_SLAB && ep.bias) {
           const float4 b = *reinterpret_cast<const float4*>(ep.bias + col);
           v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
@@ -394,7 +400,7 @@ DEVINL bool staged_epilogue_128(const GemmParams& p, f32x4 (&acc)[4][4], unsigne
           const float4 e = *reinterpret_cast<const float4*>(ep.resid + (size_t)row * ep.ldr + col);
           v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
         }
-        *reinterpret_cast<float4*>((float*)ep.out0 + (size_t)row * ep.ldo0 + col) = v;
+        *reinterpret_cast<float4*>(outp + (size_t)row * ep.ldo0 + col) = v;
       }
     }
     return true;
@@ -863,6 +869,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast_kernel(const GemmParams p
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     buf ^= 1;
+  }
+  if constexpr (EPI == EPI_F32_SLAB) {
+    GemmParams q = p;
+    q.ep.z = bc.z;
+    if (staged_epilogue_128<EPI>(q, acc, smem, m0, n0, wave, wm, wn, lane)) return;
   }
   run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, bc.z);
 }
