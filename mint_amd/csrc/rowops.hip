@@ -87,16 +87,28 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     const float mu = mean[row], rs = rstd[row];
     const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
     const bf16x4* dhr = reinterpret_cast<const bf16x4*>(dh + (size_t)row * ld16);
+    const float4* rr4 = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * C) : nullptr;
+    // all three input rows are requested before the first reduction: the residual-gradient row is not
+    // needed until after the two wave reductions, so its latency hides behind them
+    float4 xv[MAXV], rv[MAXV];
+    bf16x4 dv[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int idx = lane + i * 64;
+      if (idx < nv) {
+        xv[i] = xr[idx];
+        dv[i] = dhr[idx];
+        rv[i] = rr4 ? rr4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
     float4 xh[MAXV], dy[MAXV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int idx = lane + i * 64;
       if (idx < nv) {
-        const float4 xv = xr[idx];
-        const bf16x4 d = dhr[idx];
-        const float d0 = (float)d[0], d1 = (float)d[1], d2 = (float)d[2], d3 = (float)d[3];
-        xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        const float d0 = (float)dv[i][0], d1 = (float)dv[i][1], d2 = (float)dv[i][2], d3 = (float)dv[i][3];
+        xh[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
         dy[i] = make_float4(d0 * gm[i].x, d1 * gm[i].y, d2 * gm[i].z, d3 * gm[i].w);
         s1 += (dy[i].x + dy[i].y) + (dy[i].z + dy[i].w);
         s2 += (dy[i].x * xh[i].x + dy[i].y * xh[i].y) + (dy[i].z * xh[i].z + dy[i].w * xh[i].w);
@@ -106,7 +118,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     }
     s1 = wave_sum(s1) * invC;
     s2 = wave_sum(s2) * invC;
-    const float4* rr4 = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * C) : nullptr;
     float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * C);
     bf16x4* dx16r = dx16 ? reinterpret_cast<bf16x4*>(dx16 + (size_t)row * ld16) : nullptr;
 #pragma unroll
@@ -116,7 +127,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
         float4 o = make_float4(rs * (dy[i].x - s1 - xh[i].x * s2), rs * (dy[i].y - s1 - xh[i].y * s2),
                                rs * (dy[i].z - s1 - xh[i].z * s2), rs * (dy[i].w - s1 - xh[i].w * s2));
         if (rr4) {
-          const float4 r = rr4[idx];
+          const float4 r = rv[i];
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
           ar[i].x += r.x; ar[i].y += r.y; ar[i].z += r.z; ar[i].w += r.w;
         }
