@@ -163,7 +163,13 @@ struct FactHandle {
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> ev;
   size_t ev_i = 0;
-  hipEvent_t ev_dpre_free = nullptr, ev_dqkv_free = nullptr;  // side-stream readers of dpre / dqkv done
+  // Backward scratch that the wgrad stream reads is double-buffered (layer parity) so the dgrad chain
+  // only ever waits for the wgrad GEMMs of TWO layers ago, never for the ones just enqueued.
+  bf16_t *dpre_pp[2] = {nullptr, nullptr}, *dqkv_pp[2] = {nullptr, nullptr};
+  bf16_t* dx16_alt = nullptr;  // bf16 gradient at x_mid (the layer-boundary gradient stays in the caller's dx16)
+  hipEvent_t ev_dpre_free[2] = {nullptr, nullptr}, ev_dqkv_free[2] = {nullptr, nullptr};
+  hipEvent_t ev_xalt_free = nullptr;  // wgrad Wo of the previous layer finished reading dx16_alt
+  unsigned bw_i = 0;
   // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
   fact_grad_cb cb = nullptr;
   void* cb_user = nullptr;
@@ -371,8 +377,13 @@ void layout_work(FactHandle* h, Bump& b) {
     h->dxa = b.take<float>(Ma * d);
     h->dxa16 = b.take<bf16_t>(Ma * dp);
     h->dh = b.take<bf16_t>(Mc * dp);
-    h->dpre = b.take<bf16_t>(Mc * ffmax);
-    h->dqkv = b.take<bf16_t>(Mc * h->cross.qp);
+    for (int q = 0; q < 2; ++q) {
+      h->dpre_pp[q] = b.take<bf16_t>(Mc * ffmax);
+      h->dqkv_pp[q] = b.take<bf16_t>(Mc * h->cross.qp);
+    }
+    h->dpre = h->dpre_pp[0];
+    h->dqkv = h->dqkv_pp[0];
+    h->dx16_alt = b.take<bf16_t>(Mc * dp);
     h->dorow = b.take<bf16_t>(rowmax);
     h->dsum = b.take<float>(lsemax);
     h->ln_ws = b.take<float>(ln_bwd_ws_floats((int)Mc, d));
@@ -623,57 +634,63 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx
   LayerP& p = st.lp[l];
   LayerA& a = st.la[l];
   // The wgrad GEMMs (and the b1 column sum) go to the side stream; the dgrad / attention / LayerNorm
-  // chain stays on `s`.  Events order every producer->consumer and every buffer re-use (dx16 is
-  // rewritten in place by the LayerNorm backward, dpre / dqkv by the next layer).
+  // chain stays on `s`.  Events order every producer->consumer and every buffer re-use.  The buffers
+  // both streams touch are double-buffered by layer parity (dpre, dqkv) or split in two (the bf16
+  // gradient at x_mid goes to dx16_alt, the one at the layer boundary stays in dx16), so the main
+  // stream's write-after-read waits refer to wgrad GEMMs enqueued half a layer to two layers earlier.
   hipStream_t w = side_of(h, s);
   const bool two = (w != s);
+  const int q = (int)(h->bw_i++ & 1);
+  bf16_t* dpre = h->dpre_pp[q];
+  bf16_t* dqkv = h->dqkv_pp[q];
+  bf16_t* dxm16 = h->dx16_alt;
   // ---- MLP block: x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
   if (two) stream_after(h, s, w);  // dx16 ready
   CHK(wgrad(h, a.g, fp, ff, dx16, dp, d, M, G(h, p.w2.w), d, w));
   hipEvent_t e_w2 = two ? stream_mark(h, w) : nullptr;
-  if (two && h->ev_dpre_free) (void)hipStreamWaitEvent(s, h->ev_dpre_free, 0);
+  if (two && h->ev_dpre_free[q]) (void)hipStreamWaitEvent(s, h->ev_dpre_free[q], 0);
   {
     GemmParams g = gp(dx16, dp, p.w2.s, p.w2.lds, M, ff, d);
-    g.ep.out0 = h->dpre; g.ep.ldo0 = fp; g.ep.pre = a.pre; g.ep.ldp = fp;
+    g.ep.out0 = dpre; g.ep.ldo0 = fp; g.ep.pre = a.pre; g.ep.ldp = fp;
     CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
   }
   if (two) stream_after(h, s, w);  // dpre ready
-  CHK(wgrad(h, a.h2, dp, d, h->dpre, fp, ff, M, G(h, p.w1.w), ff, w));
-  CHK(launch_colsum_bf16(h->dpre, fp, G(h, p.b1), M, ff, ff, w));
-  if (two) h->ev_dpre_free = stream_mark(h, w);
+  CHK(wgrad(h, a.h2, dp, d, dpre, fp, ff, M, G(h, p.w1.w), ff, w));
+  CHK(launch_colsum_bf16(dpre, fp, G(h, p.b1), M, ff, ff, w));
+  if (two) h->ev_dpre_free[q] = stream_mark(h, w);
   {
-    GemmParams g = gp(h->dpre, fp, p.w1.s, p.w1.lds, M, d, ff);
+    GemmParams g = gp(dpre, fp, p.w1.s, p.w1.lds, M, d, ff);
     g.ep.out0 = h->dh; g.ep.ldo0 = dp;
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
-  if (two) (void)hipStreamWaitEvent(s, e_w2, 0);  // wgrad W2 finished reading dx16
-  CHK(launch_ln_bwd(h->dh, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, dx16, G(h, p.ln2_g),
+  if (two && h->ev_xalt_free) (void)hipStreamWaitEvent(s, h->ev_xalt_free, 0);  // previous layer's wgrad Wo read dx16_alt
+  CHK(launch_ln_bwd(h->dh, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, dxm16, G(h, p.ln2_g),
                     G(h, p.ln2_b), G(h, p.b2), h->ln_ws, M, d, dp, s));
   // ---- attention block: x_mid = x_in + Wo attn(Wqkv LN1(x_in)) + bo
-  if (two) stream_after(h, s, w);  // new dx16 ready
-  CHK(wgrad(h, a.a, dp, d, dx16, dp, d, M, G(h, p.wo.w), d, w));
-  hipEvent_t e_wo = two ? stream_mark(h, w) : nullptr;
+  if (two) stream_after(h, s, w);  // dxm16 ready
+  CHK(wgrad(h, a.a, dp, d, dxm16, dp, d, M, G(h, p.wo.w), d, w));
+  if (two) h->ev_xalt_free = stream_mark(h, w);
   {
-    GemmParams g = gp(dx16, dp, p.wo.s, p.wo.lds, M, d, d);
+    GemmParams g = gp(dxm16, dp, p.wo.s, p.wo.lds, M, d, d);
     bf16_t* row[1] = {h->dorow};
     heads_ep(g.ep, st, row, 1);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
-  if (two && h->ev_dqkv_free) (void)hipStreamWaitEvent(s, h->ev_dqkv_free, 0);
+  if (two && h->ev_dqkv_free[q]) (void)hipStreamWaitEvent(s, h->ev_dqkv_free[q], 0);
   {
     AttnParams ap = attn_params(st, a, B);
-    ap.dorow = h->dorow; ap.dsum = h->dsum; ap.dqkv = h->dqkv;
+    ap.dorow = h->dorow; ap.dsum = h->dsum; ap.dqkv = dqkv;
     CHK(launch_attn_bwd(ap, s));
   }
   if (two) stream_after(h, s, w);  // dqkv ready
-  CHK(wgrad(h, a.h1, dp, d, h->dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w));
-  if (two) h->ev_dqkv_free = stream_mark(h, w);
+  CHK(wgrad(h, a.h1, dp, d, dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w));
+  if (two) h->ev_dqkv_free[q] = stream_mark(h, w);
   {
-    GemmParams g = gp(h->dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
+    GemmParams g = gp(dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
     g.ep.out0 = h->dh; g.ep.ldo0 = dp;
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
-  if (two) (void)hipStreamWaitEvent(s, e_wo, 0);  // wgrad Wo finished reading dx16
+  if (two) (void)hipStreamWaitEvent(s, e_w2, 0);  // this layer's wgrad W2 finished reading dx16
   CHK(launch_ln_bwd(h->dh, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, dx16, G(h, p.ln1_g),
                     G(h, p.ln1_b), G(h, p.bo), h->ln_ws, M, d, dp, s));
   return 0;
@@ -988,8 +1005,9 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
     stream_after(h, h->opt, s);
     h->adam_pending = false;
   }
-  h->ev_dpre_free = nullptr;
-  h->ev_dqkv_free = nullptr;
+  // the caller's stream has joined the side stream: no reader of the backward scratch is left
+  h->ev_dpre_free[0] = h->ev_dpre_free[1] = h->ev_dqkv_free[0] = h->ev_dqkv_free[1] = nullptr;
+  h->ev_xalt_free = nullptr;
   return 0;
 }
 
