@@ -166,9 +166,9 @@ struct FactHandle {
   // Backward scratch that the wgrad stream reads is double-buffered (layer parity) so the dgrad chain
   // only ever waits for the wgrad GEMMs of TWO layers ago, never for the ones just enqueued.
   bf16_t *dpre_pp[2] = {nullptr, nullptr}, *dqkv_pp[2] = {nullptr, nullptr};
-  bf16_t* dx16_alt = nullptr;  // bf16 gradient at x_mid (the layer-boundary gradient stays in the caller's dx16)
-  hipEvent_t ev_dpre_free[2] = {nullptr, nullptr}, ev_dqkv_free[2] = {nullptr, nullptr};
-  hipEvent_t ev_xalt_free = nullptr;  // wgrad Wo of the previous layer finished reading dx16_alt
+  bf16_t *xmid_pp[2] = {nullptr, nullptr};  // bf16 gradient at x_mid
+  bf16_t *xb_pp[2] = {nullptr, nullptr};    // bf16 gradient at the layer boundary (output of layer parity q)
+  hipEvent_t ev_batch[2] = {nullptr, nullptr};  // wgrad batch of the last layer of parity q finished
   unsigned bw_i = 0;
   // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
   fact_grad_cb cb = nullptr;
@@ -383,7 +383,10 @@ void layout_work(FactHandle* h, Bump& b) {
     }
     h->dpre = h->dpre_pp[0];
     h->dqkv = h->dqkv_pp[0];
-    h->dx16_alt = b.take<bf16_t>(Mc * dp);
+    for (int q = 0; q < 2; ++q) {
+      h->xmid_pp[q] = b.take<bf16_t>(Mc * dp);
+      h->xb_pp[q] = b.take<bf16_t>(Mc * dp);
+    }
     h->dorow = b.take<bf16_t>(rowmax);
     h->dsum = b.take<float>(lsemax);
     h->ln_ws = b.take<float>(ln_bwd_ws_floats((int)Mc, d));
@@ -628,71 +631,73 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
   return 0;
 }
 
-// On entry dx / dx16 hold dL/dx_out of layer l; on exit dL/dx_in.
-int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t* dx16, hipStream_t s) {
+// On entry dx / dx16 hold dL/dx_out of layer l; on exit dL/dx_in (dx in place, dx16 re-pointed to the
+// boundary buffer this layer wrote).
+//
+// Stream plan: the dgrad / attention / LayerNorm chain stays on `s`; the four wgrad GEMMs and the b1 column
+// sum of the layer go to the side stream as ONE batch behind ONE event recorded after the attention
+// backward (an event record costs the recording stream ~7 us of dispatch bubble on MI355X - four per layer
+// were 0.45 ms per step).  Every buffer both streams touch exists twice, indexed by layer parity q:
+//   dpre[q], dqkv[q], xmid[q] : written by this layer, read by this layer's batch; previous writer/readers =
+//                               layer-2 -> the main stream waits for batch(layer-2) at layer entry;
+//   xb[q]                     : this layer's output gradient; it was the INPUT of layer-1, read by
+//                               batch(layer-1) -> waited for just before the last LayerNorm backward.
+// Both waits refer to work enqueued one to two layers earlier, so they are almost always already satisfied.
+int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& dx16, hipStream_t s) {
   const int M = B * st.n, d = st.d, ff = st.ff, dp = st.dp, fp = st.fp, qp = st.qp;
   LayerP& p = st.lp[l];
   LayerA& a = st.la[l];
-  // The wgrad GEMMs (and the b1 column sum) go to the side stream; the dgrad / attention / LayerNorm
-  // chain stays on `s`.  Events order every producer->consumer and every buffer re-use.  The buffers
-  // both streams touch are double-buffered by layer parity (dpre, dqkv) or split in two (the bf16
-  // gradient at x_mid goes to dx16_alt, the one at the layer boundary stays in dx16), so the main
-  // stream's write-after-read waits refer to wgrad GEMMs enqueued half a layer to two layers earlier.
   hipStream_t w = side_of(h, s);
   const bool two = (w != s);
   const int q = (int)(h->bw_i++ & 1);
   bf16_t* dpre = h->dpre_pp[q];
   bf16_t* dqkv = h->dqkv_pp[q];
-  bf16_t* dxm16 = h->dx16_alt;
+  bf16_t* xmid16 = h->xmid_pp[q];
+  bf16_t* xout16 = h->xb_pp[q];
+  const bf16_t* xin16 = dx16;
+  if (two && h->ev_batch[q]) (void)hipStreamWaitEvent(s, h->ev_batch[q], 0);
   // ---- MLP block: x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
-  if (two) stream_after(h, s, w);  // dx16 ready
-  CHK(wgrad(h, a.g, fp, ff, dx16, dp, d, M, G(h, p.w2.w), d, w));
-  hipEvent_t e_w2 = two ? stream_mark(h, w) : nullptr;
-  if (two && h->ev_dpre_free[q]) (void)hipStreamWaitEvent(s, h->ev_dpre_free[q], 0);
   {
-    GemmParams g = gp(dx16, dp, p.w2.s, p.w2.lds, M, ff, d);
+    GemmParams g = gp(xin16, dp, p.w2.s, p.w2.lds, M, ff, d);
     g.ep.out0 = dpre; g.ep.ldo0 = fp; g.ep.pre = a.pre; g.ep.ldp = fp;
     CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
   }
-  if (two) stream_after(h, s, w);  // dpre ready
-  CHK(wgrad(h, a.h2, dp, d, dpre, fp, ff, M, G(h, p.w1.w), ff, w));
-  CHK(launch_colsum_bf16(dpre, fp, G(h, p.b1), M, ff, ff, w));
-  if (two) h->ev_dpre_free[q] = stream_mark(h, w);
   {
     GemmParams g = gp(dpre, fp, p.w1.s, p.w1.lds, M, d, ff);
     g.ep.out0 = h->dh; g.ep.ldo0 = dp;
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
-  if (two && h->ev_xalt_free) (void)hipStreamWaitEvent(s, h->ev_xalt_free, 0);  // previous layer's wgrad Wo read dx16_alt
-  CHK(launch_ln_bwd(h->dh, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, dxm16, G(h, p.ln2_g),
+  CHK(launch_ln_bwd(h->dh, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, G(h, p.ln2_g),
                     G(h, p.ln2_b), G(h, p.b2), h->ln_ws, M, d, dp, s));
   // ---- attention block: x_mid = x_in + Wo attn(Wqkv LN1(x_in)) + bo
-  if (two) stream_after(h, s, w);  // dxm16 ready
-  CHK(wgrad(h, a.a, dp, d, dxm16, dp, d, M, G(h, p.wo.w), d, w));
-  if (two) h->ev_xalt_free = stream_mark(h, w);
   {
-    GemmParams g = gp(dxm16, dp, p.wo.s, p.wo.lds, M, d, d);
+    GemmParams g = gp(xmid16, dp, p.wo.s, p.wo.lds, M, d, d);
     bf16_t* row[1] = {h->dorow};
     heads_ep(g.ep, st, row, 1);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
-  if (two && h->ev_dqkv_free[q]) (void)hipStreamWaitEvent(s, h->ev_dqkv_free[q], 0);
   {
     AttnParams ap = attn_params(st, a, B);
     ap.dorow = h->dorow; ap.dsum = h->dsum; ap.dqkv = dqkv;
     CHK(launch_attn_bwd(ap, s));
   }
-  if (two) stream_after(h, s, w);  // dqkv ready
+  // ---- the layer's weight gradients: one batch on the side stream
+  if (two) stream_after(h, s, w);  // xin16, dpre, xmid16, dqkv are all final
+  CHK(wgrad(h, a.g, fp, ff, xin16, dp, d, M, G(h, p.w2.w), d, w));
+  CHK(wgrad(h, a.h2, dp, d, dpre, fp, ff, M, G(h, p.w1.w), ff, w));
+  CHK(launch_colsum_bf16(dpre, fp, G(h, p.b1), M, ff, ff, w));
+  CHK(wgrad(h, a.a, dp, d, xmid16, dp, d, M, G(h, p.wo.w), d, w));
   CHK(wgrad(h, a.h1, dp, d, dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w));
-  if (two) h->ev_dqkv_free[q] = stream_mark(h, w);
+  if (two) h->ev_batch[q] = stream_mark(h, w);
   {
     GemmParams g = gp(dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
     g.ep.out0 = h->dh; g.ep.ldo0 = dp;
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
-  if (two) (void)hipStreamWaitEvent(s, e_w2, 0);  // this layer's wgrad W2 finished reading dx16
-  CHK(launch_ln_bwd(h->dh, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, dx16, G(h, p.ln1_g),
+  if (two && h->ev_batch[q ^ 1]) (void)hipStreamWaitEvent(s, h->ev_batch[q ^ 1], 0);  // readers of xb[q]
+  CHK(launch_ln_bwd(h->dh, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, G(h, p.ln1_g),
                     G(h, p.ln1_b), G(h, p.bo), h->ln_ws, M, d, dp, s));
+  dx16 = xout16;
   return 0;
 }
 
@@ -711,6 +716,7 @@ int embed_backward(FactHandle* h, Stack& st, int B, float* dx, bf16_t* dx16, hip
   hipStream_t w = side_of(h, s);  // all wgrads share the side stream (and its transpose scratch)
   if (w != s) stream_after(h, s, w);
   CHK(wgrad(h, st.xin16, st.featp, st.feat, dx16, st.dp, st.d, M, G(h, st.emb.w), st.d, w));
+  if (w != s) h->ev_batch[0] = h->ev_batch[1] = stream_mark(h, w);  // it read the last boundary buffer
   CHK(launch_colsum_f32(dx, st.d, G(h, st.emb_b), M, st.d, st.d, s));
   CHK(launch_possum(dx, G(h, st.pos), B, st.n, st.d, s));
   return 0;
@@ -989,16 +995,19 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   // head, cross layers L-1..0, audio stack, motion stack (fact_set_grad_callback).
   h->cb_bucket = 0;
   CHK(notify_grads(h, s));  // head
+  bf16_t* g16 = h->dx16;  // bf16 gradient at the current layer boundary (re-pointed by every layer)
   for (int l = cr.L - 1; l >= 0; --l) {
-    CHK(layer_backward(h, cr, l, B, h->dx, h->dx16, s));
+    CHK(layer_backward(h, cr, l, B, h->dx, g16, s));
     CHK(notify_grads(h, s));  // cross layer l
   }
   CHK(launch_split_grad(h->dx, B, mo.n, au.n, d, h->dxm, h->dxm16, h->dxa, h->dxa16, cr.dp, s));
-  for (int l = au.L - 1; l >= 0; --l) CHK(layer_backward(h, au, l, B, h->dxa, h->dxa16, s));
-  CHK(embed_backward(h, au, B, h->dxa, h->dxa16, s));
+  g16 = h->dxa16;
+  for (int l = au.L - 1; l >= 0; --l) CHK(layer_backward(h, au, l, B, h->dxa, g16, s));
+  CHK(embed_backward(h, au, B, h->dxa, g16, s));
   CHK(notify_grads(h, s));  // audio stack
-  for (int l = mo.L - 1; l >= 0; --l) CHK(layer_backward(h, mo, l, B, h->dxm, h->dxm16, s));
-  CHK(embed_backward(h, mo, B, h->dxm, h->dxm16, s));
+  g16 = h->dxm16;
+  for (int l = mo.L - 1; l >= 0; --l) CHK(layer_backward(h, mo, l, B, h->dxm, g16, s));
+  CHK(embed_backward(h, mo, B, h->dxm, g16, s));
   CHK(notify_grads(h, s));  // motion stack
   if (side_of(h, s) != s) stream_after(h, h->side, s);  // join: the caller's stream sees all gradients
   if (h->adam_pending && !h->cb) {  // fused optimizer step: join the optimizer stream, step is complete
@@ -1006,8 +1015,7 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
     h->adam_pending = false;
   }
   // the caller's stream has joined the side stream: no reader of the backward scratch is left
-  h->ev_dpre_free[0] = h->ev_dpre_free[1] = h->ev_dqkv_free[0] = h->ev_dqkv_free[1] = nullptr;
-  h->ev_xalt_free = nullptr;
+  h->ev_batch[0] = h->ev_batch[1] = nullptr;
   return 0;
 }
 

@@ -6,7 +6,6 @@ d = sys.argv[1]
 db = glob.glob(d + "/**/*.db", recursive=True)[0]
 c = sqlite3.connect(db)
 cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
-print("kernels view columns:", cols)
 rows = list(c.execute("select name, start, end, stream_id, queue_id from kernels order by start"))
 # find step boundaries: mse_loss_kernel appears once per step
 idx = [i for i, r in enumerate(rows) if "mse_loss" in r[0]]
@@ -40,8 +39,13 @@ gaps = collections.defaultdict(lambda: [0, 0.0])
 tot_gap = 0
 for p, n in zip(main, main[1:]):
     g = (n[1] - p[2]) / 1e3
-    key = p[0][:40].split("(")[0] + " -> " + n[0][:40].split("(")[0]
+    def short(nm):
+        nm = nm.replace("void ", "").replace("(anonymous namespace)::", "")
+        if nm.startswith("_ZN12_GLOBAL__N_1"):
+            nm = nm[len("_ZN12_GLOBAL__N_1"):].lstrip("0123456789")
+        return nm.split("(")[0][:34]
+    key = short(p[0]) + " -> " + short(n[0])
     gaps[key][0] += 1; gaps[key][1] += g; tot_gap += g
 print("main stream: sum of gaps %.1f us over %d kernels" % (tot_gap, len(main)))
-for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
-    print("  %-90s n=%3d total %.1f us avg %.2f" % (k, v[0], v[1], v[1] / v[0]))
+for k, v in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:22]:
+    print("  %-72s n=%3d total %6.1f us avg %5.2f" % (k, v[0], v[1], v[1] / v[0]))
