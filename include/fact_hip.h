@@ -144,13 +144,6 @@ int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int
 /* C(MoxNo) += A^T B with A [K][Mo], B [K][No] bf16 (wgrad form), f32 atomic accumulate. */
 int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int No, int K,
                     float* out, int ldo, int splitk, int use_tr, void* scratch, void* stream);
-/* Grouped, K-balanced wgrad: out[q](Mo[q] x No[q]) += A[q]^T B[q] for q < nprob (<= 6), all with the same
- * K (multiple of 64), as ONE launch whose workgroups (<= max_wgs) get equal numbers of K steps
- * (mint_amd/csrc/gemm.h).  Call with scratch == NULL to get the scratch size in *scratch_needed. */
-int fact_op_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, const void* const* B,
-                            const int* ldb, const int* Mo, const int* No, float* const* out,
-                            const int* ldo, int K, int max_wgs, void* scratch, size_t scratch_bytes,
-                            size_t* scratch_needed, void* stream);
 int fact_op_ln_fwd(const float* x, const float* gamma, const float* beta, void* h, float* mean,
                    float* rstd, int M, int C, float eps, void* stream);
 int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
@@ -174,7 +167,7 @@ int fact_probe_tr(const float* lds_vals, int n, const int* byte_addrs, float* ou
 int fact_debug_force_generic_gemm(int on);
 /* Test knob: 1 = use the tiled (streaming) attention kernels even when the LDS-resident ones fit. */
 int fact_debug_attn_force_tiled(int on);
-/* Test/bench knob: NT GEMM kernel choice (0 auto, 1 two-stage 128x128, 2 ring 128x128, 3 ring 256x128). */
+/* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 6 / 7 = big-tile 288x256 / 256x256). */
 int fact_debug_gemm_nt_variant(int v);
 /* Test/bench knob: NT GEMM tile band height (tile order inside an XCD; 1 = row-major, default 8). */
 int fact_debug_gemm_nt_band(int band);

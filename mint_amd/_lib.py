@@ -63,8 +63,6 @@ SIGNATURES = {
     "fact_op_gemm_nt": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i,
                              _vp, _i, _vp]),
     "fact_op_gemm_tn": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
-    "fact_op_gemm_tn_grouped": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_i),
-                                     C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), _i, _i, _vp, _sz, C.POINTER(_sz), _vp]),
     "fact_op_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "fact_op_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fact_op_attention_scratch": (_sz, [_i, _i, _i, _i]),

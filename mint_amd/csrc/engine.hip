@@ -1174,30 +1174,6 @@ int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int 
   return 0;
 }
 
-int fact_op_gemm_tn_grouped(int nprob, const void* const* A, const int* lda, const void* const* B,
-                            const int* ldb, const int* Mo, const int* No, float* const* out,
-                            const int* ldo, int K, int max_wgs, void* scratch, size_t scratch_bytes,
-                            size_t* scratch_needed, void* stream) {
-  if (nprob < 1 || nprob > TN_MAX_PROB) return fail(-1, "nprob outside [1, 6]");
-  TnGroupParams p;
-  memset(&p, 0, sizeof(p));
-  p.nprob = nprob;
-  p.K = K;
-  for (int q = 0; q < nprob; ++q) {
-    p.pr[q].A = (const bf16_t*)A[q]; p.pr[q].lda = lda[q];
-    p.pr[q].B = (const bf16_t*)B[q]; p.pr[q].ldb = ldb[q];
-    p.pr[q].out = out ? out[q] : nullptr; p.pr[q].ldo = ldo[q];
-    p.pr[q].Mo = Mo[q]; p.pr[q].No = No[q];
-  }
-  const size_t need = tn_grouped_slab_floats(p, max_wgs) * sizeof(float);
-  if (scratch_needed) *scratch_needed = need;
-  if (!scratch) return need ? 0 : fail(-1, "invalid grouped wgrad problem");
-  if (!need || scratch_bytes < need) return fail(-1, "grouped wgrad scratch too small");
-  p.slab = (float*)scratch;
-  CHK(launch_gemm_tn_grouped(p, max_wgs, (hipStream_t)stream));
-  return 0;
-}
-
 int fact_op_ln_fwd(const float* x, const float* gamma, const float* beta, void* hh, float* mean,
                    float* rstd, int M, int C, float eps, void* stream) {
   CHK(launch_ln_fwd(x, gamma, beta, (bf16_t*)hh, C, mean, rstd, M, C, eps, (hipStream_t)stream));

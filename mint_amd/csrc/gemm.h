@@ -48,37 +48,12 @@ struct GemmParams {
   int M, N, K;
   int splitk;
   int force_generic;  // tests: use the register-staged fallback kernel
-  int tile256;        // TN: use the 256x128 ring kernel (M is the 256-tiled dimension)
   int band;           // NT tile order: band height in m-tiles (0 = default, 1 = row-major)
   EpiParams ep;
 };
 
-// Grouped, K-balanced wgrad: up to TN_MAX_PROB independent dW_q[Mo_q][No_q] += A_q^T B_q problems that
-// share the reduction length K (tokens) run as ONE launch.  The (tile, K-step) units of all problems
-// are laid end to end and cut into equal contiguous ranges, one per workgroup (<= max_wgs, ~2 per CU),
-// so every CU gets the same number of K steps whatever the weight shapes are.  A workgroup writes one
-// fp32 partial tile ("segment") per tile it touches into `slab`; a second kernel sums the segments of
-// each tile and accumulates into dW.  Segment ids are a closed form of the unit index, so neither
-// kernel needs a work list.  Requires K % 64 == 0.
-constexpr int TN_MAX_PROB = 6;
-struct TnProblem {
-  const bf16_t* A;  // [K][Mo] (lda)
-  const bf16_t* B;  // [K][No] (ldb)
-  float* out;       // [Mo][No] (ldo), accumulated
-  int lda, ldb, ldo, Mo, No;
-  int tn, tile_begin;  // filled by the launcher
-};
-struct TnGroupParams {
-  TnProblem pr[TN_MAX_PROB];
-  int nprob, K;
-  int kiters, per, total, ntiles, lcm;  // filled by the launcher
-  float* slab;
-};
-size_t tn_grouped_slab_floats(const TnGroupParams& p, int max_wgs);
-int launch_gemm_tn_grouped(TnGroupParams& p, int max_wgs, hipStream_t stream);
-
 // Launchers. Return 0 on success, negative on invalid arguments.
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);
 int launch_gemm_tn(int epi, const GemmParams& p, hipStream_t stream);
-void gemm_set_nt_variant(int v);  // 0 auto, 1 two-stage, 2 ring 128x128, 3 ring 256x128
+void gemm_set_nt_variant(int v);  // 0 auto, 1 = 128x128 kernel, 6 / 7 = big-tile 288x256 / 256x256
 void gemm_set_nt_band(int band);   // NT tile band height (1 = row-major)

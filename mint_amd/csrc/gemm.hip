@@ -482,13 +482,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast_kernel(const GemmParams p
 }
 
 // ------------------------------------------------------------------------------------------
-// ring NT: (WM*64) x 128 block tile, 2*WM waves, BK = 32 stages in an NSTAGE-deep LDS ring.
-// The LDS-DMA latency under load (~1-1.5 us) is several K steps long, so NSTAGE-1 stages stay in
-// flight: each step waits with a COUNTED vmcnt for the oldest stage only, crosses one raw
-// s_barrier, re-arms the slot freed by the previous step and runs 16 MFMAs per wave.
-// Stage image: [rows][32 k] = 64-byte rows; logical 16-byte chunk c of row r sits at position
-// c ^ G[(r>>2)&3], G = {0,2,3,1}: every ds_read_b128 service group (rows {0-3,12-15} of one k-chunk
-// plus rows {4-11} of the next) lands on 16 distinct 16-byte bank slots.
+// Stage image of the big-tile kernel's LDS ring: [rows][32 k] = 64-byte rows; logical 16-byte chunk c of
+// row r sits at position c ^ G[(r>>2)&3], G = {0,2,3,1}: every ds_read_b128 service group (rows {0-3,12-15}
+// of one k-chunk plus rows {4-11} of the next) lands on 16 distinct 16-byte bank slots.  Stages are
+// retired with COUNTED vmcnt waits (wait_stages): NSTAGE-1 stages stay in flight across the barriers.
 // ------------------------------------------------------------------------------------------
 DEVINL int ring_g(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
@@ -518,95 +515,6 @@ DEVINL void wait_stages(int stages_after) {
   }
 }
 
-// BKR = 64: 128-byte rows (full cache lines per DMA row, chunk position c ^ (r&7));
-// BKR = 32: 64-byte rows (G swizzle above).
-template <int EPI, int WM, int NSTAGE, int BKR>
-__global__ __launch_bounds__(WM * 128, 2) void gemm_nt_ring_kernel(const GemmParams p) {
-  constexpr int RBM = WM * 64;                 // block rows
-  constexpr int NW = WM * 2;                   // waves
-  constexpr int ROWB = BKR * 2;                // bytes per tile row
-  constexpr int RPP = 1024 / ROWB;             // rows per 1-KiB DMA piece
-  constexpr int CPR = ROWB / 16;               // 16-byte chunks per row
-  constexpr int A_BYTES = RBM * ROWB;          // one stage of A
-  constexpr int STAGE_BYTES = A_BYTES + 128 * ROWB;
-  constexpr int APW = RBM / RPP / NW;          // A pieces per wave
-  constexpr int BPW = 128 / RPP / NW;          // B pieces per wave
-  constexpr int LPS = APW + BPW;               // LDS-DMA loads per thread per stage
-  constexpr int DIST = NSTAGE - 1;             // prefetch distance (<= 5)
-  constexpr int KSUB = BKR / 32;
-  static_assert(DIST >= 1 && DIST <= 5 && APW >= 1 && BPW >= 1 && 4 * LPS < 64, "ring geometry");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // block -> tile (same XCD-contiguous re-deal as block_coord, with this kernel's tile height)
-  const int tn = (p.N + BN - 1) / BN;
-  int m0, n0;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    n0 = (id % tn) * BN;
-    m0 = (id / tn) * RBM;
-  }
-  const int nk = (p.K + BKR - 1) / BKR;
-
-  f32x4 acc[4][4];
-  zero_acc(acc);
-
-  // DMA piece = RPP rows; lane -> row lane/CPR, LDS chunk position lane%CPR <- logical chunk
-  const int lrow = lane / CPR;
-  const int lchunk = (lane % CPR) ^ ring_swz<BKR>(lrow);
-  const bf16_t* asrc[APW];
-  const bf16_t* bsrc[BPW];
-#pragma unroll
-  for (int i = 0; i < APW; ++i)
-    asrc[i] = p.A + (size_t)min(m0 + (wave * APW + i) * RPP + lrow, p.M - 1) * p.lda;
-#pragma unroll
-  for (int i = 0; i < BPW; ++i)
-    bsrc[i] = p.B + (size_t)min(n0 + (wave * BPW + i) * RPP + lrow, p.N - 1) * p.ldb;
-
-  auto stage = [&](int kt) {
-    unsigned char* base = smem + (kt % NSTAGE) * STAGE_BYTES;
-    int k = kt * BKR + lchunk * 8;
-    if (k >= p.K) k -= 32;  // K tail of a 64-deep stage (K % 64 == 32): duplicate, ks = 1 is skipped
-#pragma unroll
-    for (int i = 0; i < APW; ++i) glds16(asrc[i] + k, base + (wave * APW + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < BPW; ++i) glds16(bsrc[i] + k, base + A_BYTES + (wave * BPW + i) * 1024);
-  };
-
-#pragma unroll
-  for (int s = 0; s < DIST; ++s)
-    if (s < nk) stage(s);
-
-  for (int kt = 0; kt < nk; ++kt) {
-    wait_stages<LPS>(min(DIST - 1, nk - 1 - kt));
-    __builtin_amdgcn_s_barrier();
-    if (kt + DIST < nk) stage(kt + DIST);
-    const unsigned char* As = smem + (kt % NSTAGE) * STAGE_BYTES;
-    const unsigned char* Bs = As + A_BYTES;
-    const int nks = (KSUB == 2 && p.K - kt * BKR < BKR) ? 1 : KSUB;
-#pragma unroll
-    for (int ks = 0; ks < KSUB; ++ks) {
-      if (ks < nks) {
-        bf16x8 af[4], bfr[4];
-        const int chunk = ks * 4 + (lane >> 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = ring_frag<BKR>(As, wm * 64 + i * 16 + (lane & 15), chunk);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = ring_frag<BKR>(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = kSwap<EPI> ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
-      }
-    }
-  }
-  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane);
-}
-
 // ------------------------------------------------------------------------------------------
 // big-tile NT: (32*MR) x 256 block tile, 8 waves = 2 (M) x 4 (N), each wave a (16*MR) x 64 sub-tile
 // (MR x 4 MFMA tiles, MR = 8 or 9), 32-deep K stages in a 4-deep LDS ring with counted vmcnt.
@@ -615,7 +523,7 @@ __global__ __launch_bounds__(WM * 128, 2) void gemm_nt_ring_kernel(const GemmPar
 // carries 2x the FLOPs per DMA byte, so the LDS pipe and the DMA issue slots stop being the limit.
 // One workgroup per CU (136 KiB of LDS): the tile height is picked so that the grid is <= 256
 // workgroups (M = 5760 -> MR = 9: 20 x 12 tiles of 288 x 256 for the FFN1 shape).
-// Stage image: [rows][32 k] 64-byte rows, chunk swizzle ring_g (see the ring kernel above).
+// Stage image: [rows][32 k] 64-byte rows, chunk swizzle ring_g (above).
 // ------------------------------------------------------------------------------------------
 template <int EPI, int MR>
 __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const GemmParams p) {
@@ -879,262 +787,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast_kernel(const GemmParams p
 }
 
 // ------------------------------------------------------------------------------------------
-// grouped, K-balanced TN (see gemm.h): same 128x128x64 LDS-DMA / transpose-read body as the fast TN
-// kernel; a workgroup walks its unit range [w*per, (w+1)*per) and emits one partial tile per segment.
-// Segment id of the segment that starts at unit u (u is a multiple of kiters or of per):
-//   id(u) = u/kiters + u/per - u/lcm(kiters, per)   (= number of segment boundaries in (0, u]).
-// Partial tiles are stored lane-major (slot (i*4+j), thread) so the stores are 1 KiB contiguous per
-// wave instruction; the reduce kernel undoes the MFMA layout.
-// ------------------------------------------------------------------------------------------
-DEVINL int seg_id(int u, int kiters, int per, int lcm) { return u / kiters + u / per - u / lcm; }
-
-struct TnTileCtx {  // per-lane DMA source pointers of the NEXT K step to stage, and their per-step strides
-  const bf16_t* ap[4];
-  const bf16_t* bp[4];
-  size_t astep, bstep;
-};
-
-__global__ __launch_bounds__(256, 2) void gemm_tn_grouped_kernel(const TnGroupParams p) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * TILE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  int w;
-  {  // XCD-contiguous re-deal of the workgroup index (see block_coord)
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  const int u0 = w * p.per;
-  const int uend = min(u0 + p.per, p.total);
-  if (u0 >= uend) return;
-  const int lk = lane >> 4, lp = lane & 15;
-
-  auto decode = [&](int tg, int kt, TnTileCtx& c) {
-    int q = 0;
-#pragma unroll
-    for (int i = 1; i < TN_MAX_PROB; ++i)
-      if (i < p.nprob && tg >= p.pr[i].tile_begin) q = i;
-    const bf16_t* A = p.pr[q].A;
-    const bf16_t* B = p.pr[q].B;
-    const int lda = p.pr[q].lda, ldb = p.pr[q].ldb;
-    const int t = tg - p.pr[q].tile_begin;
-    const int m0 = (t / p.pr[q].tn) * BM, n0 = (t % p.pr[q].tn) * BN;
-    c.astep = (size_t)BK * lda;
-    c.bstep = (size_t)BK * ldb;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kr = (wave * 4 + i) * 4 + lk;  // row inside a 64-deep K step
-      const int mc = ((((lp >> 1) ^ tn_f(kr)) << 1) | (lp & 1)) * 8;
-      const size_t k = (size_t)kt * BK + kr;
-      c.ap[i] = A + k * lda + min(m0 + mc, lda - 8);
-      c.bp[i] = B + k * ldb + min(n0 + mc, ldb - 8);
-    }
-  };
-  auto stage = [&](int buf, TnTileCtx& c) {
-    unsigned char* As = smem + buf * 2 * TILE_BYTES + wave * 4096;
-    unsigned char* Bs = As + TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      glds16(c.ap[i], As + i * 1024);
-      glds16(c.bp[i], Bs + i * 1024);
-      c.ap[i] += c.astep;
-      c.bp[i] += c.bstep;
-    }
-  };
-
-  // One software pipeline over the whole unit range: the first K step of the next tile is already in
-  // flight while the last step of the current tile is multiplied and its partial tile is stored.
-  TnTileCtx ctx;
-  int tg = u0 / p.kiters;
-  int kt = u0 - tg * p.kiters;
-  int seg_start = u0;
-  decode(tg, kt, ctx);
-  f32x4 acc[4][4];
-  zero_acc(acc);
-  stage(0, ctx);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int buf = 0;
-  for (int u = u0; u < uend; ++u) {
-    const bool tile_end = (kt + 1 == p.kiters);
-    if (u + 1 < uend) {
-      if (tile_end) decode(tg + 1, 0, ctx);
-      stage(buf ^ 1, ctx);
-    }
-    const unsigned char* As = smem + buf * 2 * TILE_BYTES;
-    compute_tile_tn<true>(As, As + TILE_BYTES, acc, wm, wn, lane);
-    if (tile_end || u + 1 == uend) {
-      float4* dst =
-          reinterpret_cast<float4*>(p.slab + (size_t)seg_id(seg_start, p.kiters, p.per, p.lcm) * (BM * BN)) + tid;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          dst[(i * 4 + j) * 256] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      zero_acc(acc);
-      seg_start = u + 1;
-    }
-    if (tile_end) { tg += 1; kt = 0; } else { kt += 1; }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    buf ^= 1;
-  }
-}
-
-// grid (ntiles, 4): block (tg, part) sums slots part*4 .. part*4+3 of every segment of tile tg
-__global__ __launch_bounds__(256) void tn_grouped_reduce_kernel(const TnGroupParams p) {
-  const int tg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  int q = 0;
-#pragma unroll
-  for (int i = 1; i < TN_MAX_PROB; ++i)
-    if (i < p.nprob && tg >= p.pr[i].tile_begin) q = i;
-  const int t = tg - p.pr[q].tile_begin;
-  const int m0 = (t / p.pr[q].tn) * BM, n0 = (t % p.pr[q].tn) * BN;
-  const int Mo = p.pr[q].Mo, No = p.pr[q].No, ldo = p.pr[q].ldo;
-  float* out = p.pr[q].out;
-  const int s0 = seg_id(tg * p.kiters, p.kiters, p.per, p.lcm);
-  const int s1 = seg_id((tg + 1) * p.kiters - 1, p.kiters, p.per, p.lcm);
-#pragma unroll
-  for (int ss = 0; ss < 4; ++ss) {
-    const int slot = blockIdx.y * 4 + ss;
-    const int i = slot >> 2, j = slot & 3;
-    const int row = m0 + wm * 64 + i * 16 + (lane & 15);
-    const int col0 = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-    if (row >= Mo || col0 >= No) continue;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int sgi = s0; sgi <= s1; ++sgi) {
-      const float4 v = reinterpret_cast<const float4*>(p.slab + (size_t)sgi * (BM * BN))[slot * 256 + tid];
-      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-    }
-    float* o = out + (size_t)row * ldo + col0;
-    if (col0 + 3 < No && !(ldo & 3)) {
-      float4 c = *reinterpret_cast<float4*>(o);
-      c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w;
-      *reinterpret_cast<float4*>(o) = c;
-    } else {
-      const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (col0 + r < No) o[r] += av[r];
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// ring TN (wgrad): (WM*64) x 128 output tile, 2*WM waves, 64-deep K stages in an NSTAGE LDS ring,
-// counted vmcnt + raw barrier like the NT ring.  A stage = [64 k][WM*64 m], B stage = [64 k][128 n];
-// rows are 512 / 256 bytes, the 32-byte unit swizzle u ^ f(k) of the fast TN kernel is kept (f only
-// touches the low 3 unit bits, so a 512-byte row swizzles inside each 256-byte half).
-// Requires K % 64 == 0.  Higher arithmetic intensity per LDS-DMA byte than 128x128 (85 vs 64 F/B).
-// ------------------------------------------------------------------------------------------
-template <int ROWB>
-DEVINL bf16x8 tnr_frag(const unsigned char* tile, int ks, int u, int lane) {
-  const int g = lane >> 4, s = lane & 15;
-  bf16x4 r[2];
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    const int k = ks * 32 + g * 8 + hh * 4 + (s >> 2);
-    const int off = k * ROWB + ((u ^ tn_f(k)) << 5) + (s & 3) * 8;
-    r[hh] = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(tile + off));
-  }
-  bf16x8 f = {r[0][0], r[0][1], r[0][2], r[0][3], r[1][0], r[1][1], r[1][2], r[1][3]};
-  return f;
-}
-
-template <int EPI, int WM, int NSTAGE>
-__global__ __launch_bounds__(WM * 128, 2) void gemm_tn_ring_kernel(const GemmParams p) {
-  constexpr int RBM = WM * 64;
-  constexpr int NW = WM * 2;
-  constexpr int A_ROWB = RBM * 2, B_ROWB = 256;
-  constexpr int A_BYTES = 64 * A_ROWB, B_BYTES = 64 * B_ROWB;
-  constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
-  constexpr int APW = A_BYTES / 1024 / NW, BPW = B_BYTES / 1024 / NW;
-  constexpr int LPS = APW + BPW;
-  constexpr int DIST = NSTAGE - 1;
-  constexpr int A_RPP = 1024 / A_ROWB, B_RPP = 4;  // rows per DMA piece (A_RPP: 2 for 512-byte rows)
-  static_assert(DIST >= 1 && DIST <= 5 && 4 * LPS < 64 && A_RPP >= 1, "ring geometry");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NSTAGE * STAGE_BYTES];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int tn = (p.N + BN - 1) / BN;
-  int m0, n0, z;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    z = id % p.splitk;
-    const int t = id / p.splitk;
-    n0 = (t % tn) * BN;
-    m0 = (t / tn) * RBM;
-  }
-  int kt_beg, kt_end;
-  split_range(p, z, kt_beg, kt_end);
-  if (kt_beg >= kt_end) return;
-  const int nk = kt_end - kt_beg;
-
-  f32x4 acc[4][4];
-  zero_acc(acc);
-
-  // A piece: A_RPP rows of A_ROWB bytes; lane -> row lane / (A_ROWB/16), chunk position lane % (A_ROWB/16)
-  constexpr int A_CPR = A_ROWB / 16, B_CPR = B_ROWB / 16;
-  int acol[APW], arow[APW], bcol[BPW], brow[BPW];
-#pragma unroll
-  for (int i = 0; i < APW; ++i) {
-    const int k = (wave * APW + i) * A_RPP + lane / A_CPR;
-    const int pp = lane % A_CPR;
-    const int mc = ((((pp >> 1) ^ tn_f(k)) << 1) | (pp & 1)) * 8;
-    arow[i] = k;
-    acol[i] = min(m0 + mc, p.lda - 8);
-  }
-#pragma unroll
-  for (int i = 0; i < BPW; ++i) {
-    const int k = (wave * BPW + i) * B_RPP + lane / B_CPR;
-    const int pp = lane % B_CPR;
-    const int nc = ((((pp >> 1) ^ tn_f(k)) << 1) | (pp & 1)) * 8;
-    brow[i] = k;
-    bcol[i] = min(n0 + nc, p.ldb - 8);
-  }
-  auto stage = [&](int j) {  // j-th K stage of this split
-    unsigned char* base = smem + (j % NSTAGE) * STAGE_BYTES;
-    const size_t k0 = (size_t)(kt_beg + j) * 64;
-#pragma unroll
-    for (int i = 0; i < APW; ++i)
-      glds16(p.A + (k0 + arow[i]) * p.lda + acol[i], base + (wave * APW + i) * 1024);
-#pragma unroll
-    for (int i = 0; i < BPW; ++i)
-      glds16(p.B + (k0 + brow[i]) * p.ldb + bcol[i], base + A_BYTES + (wave * BPW + i) * 1024);
-  };
-
-#pragma unroll
-  for (int s = 0; s < DIST; ++s)
-    if (s < nk) stage(s);
-
-  for (int j = 0; j < nk; ++j) {
-    wait_stages<LPS>(min(DIST - 1, nk - 1 - j));
-    __builtin_amdgcn_s_barrier();
-    if (j + DIST < nk) stage(j + DIST);
-    const unsigned char* As = smem + (j % NSTAGE) * STAGE_BYTES;
-    const unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = tnr_frag<A_ROWB>(As, ks, wm * 4 + i, lane);
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) bfr[jj] = tnr_frag<B_ROWB>(Bs, ks, wn * 4 + jj, lane);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-          acc[i][jj] = kSwap<EPI> ? mfma16(bfr[jj], af[i], acc[i][jj]) : mfma16(af[i], bfr[jj], acc[i][jj]);
-    }
-  }
-  run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, z);
-}
-
-// ------------------------------------------------------------------------------------------
 // generic kernels: register-staged, zero-filled bounds (any M, N; K % 8 == 0 for NT)
 // ------------------------------------------------------------------------------------------
 template <int EPI, bool TN>
@@ -1209,21 +861,21 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(const GemmParams p
 }
 
 int g_nt_band = 8;  // tile band height of the NT kernels (bench knob; measured: 8 >= 4 > row-major)
-int g_nt_variant = 0;  // 0 auto, 1 two-stage fast, 2 ring 128x128, 3 ring 256x128 (bench/test knob)
+int g_nt_variant = 0;  // 0 auto, 1 = 128x128 kernel, 6 / 7 = big-tile kernel 288x256 / 256x256 (bench/test knob)
 
 template <int EPI>
 int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
   if (p.band == 0) p.band = g_nt_band;
   const int tn = (p.N + BN - 1) / BN;
-  const int tiles128 = tn * ((p.M + 127) / 128), tiles256 = tn * ((p.M + 255) / 256);
+  const int tiles128 = tn * ((p.M + 127) / 128);
   if (p.force_generic || (p.K & 31)) {
     hipLaunchKernelGGL((gemm_generic_kernel<EPI, false>), dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
     return 0;
   }
   int variant = g_nt_variant;
   if (p.splitk > 1) variant = 1;
-  else if (variant == 0) variant = 1;  // measured: the 2-stage 128x128 kernel wins at every FACT shape
+  else if (variant == 0) variant = 1;  // 128x128 kernel unless the big-tile rule below takes the shape
   if constexpr (EPI != EPI_ATOMIC_F32) {
     // Big-tile kernel (one 288x256 or 256x256 workgroup per CU): taken when its rounds of 256
     // workgroups are well filled, counting tile padding: useful outputs / (rounds * 256 * tile area)
@@ -1263,14 +915,7 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
       return 0;
     }
   }
-  if (variant == 4)
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, 4, 3, 64>), dim3(tiles256), dim3(512), 0, s, p);
-  else if (variant == 3)
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, 4, 6, 32>), dim3(tiles256), dim3(512), 0, s, p);
-  else if (variant == 2)
-    hipLaunchKernelGGL((gemm_nt_ring_kernel<EPI, 2, 4, 32>), dim3(tiles128), dim3(256), 0, s, p);
-  else
-    hipLaunchKernelGGL(gemm_nt_fast_kernel<EPI>, dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(gemm_nt_fast_kernel<EPI>, dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
   return 0;
 }
 template <int EPI>
@@ -1278,12 +923,7 @@ int launch_tn_t(const GemmParams& p, hipStream_t s) {
   const int tn = (p.N + BN - 1) / BN;
   dim3 grid(tn * ((p.M + BM - 1) / BM) * p.splitk);
   if ((p.K & 63) == 0 && p.lda >= 8 && p.ldb >= 8 && !p.force_generic) {
-    // g_nt_variant >= 10 selects the 256x128 ring kernel (bench/test knob; engine sets p.tile256)
-    if (p.tile256 || g_nt_variant >= 10)
-      hipLaunchKernelGGL((gemm_tn_ring_kernel<EPI, 4, 3>), dim3(tn * ((p.M + 255) / 256) * p.splitk),
-                         dim3(512), 0, s, p);
-    else
-      hipLaunchKernelGGL(gemm_tn_fast_kernel<EPI>, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(gemm_tn_fast_kernel<EPI>, grid, dim3(256), 0, s, p);
   } else {
     hipLaunchKernelGGL((gemm_generic_kernel<EPI, true>), grid, dim3(256), 0, s, p);
   }
@@ -1301,48 +941,6 @@ int check_common(const GemmParams& p, int epi) {
 }
 
 }  // namespace
-
-namespace {
-int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
-int tn_group_plan(TnGroupParams& p, int max_wgs) {
-  if (p.nprob < 1 || p.nprob > TN_MAX_PROB || p.K <= 0 || (p.K & 63) || max_wgs < 1) return -1;
-  int tiles = 0;
-  for (int q = 0; q < p.nprob; ++q) {
-    TnProblem& r = p.pr[q];
-    if (r.Mo <= 0 || r.No <= 0 || (r.lda & 7) || (r.ldb & 7) || r.lda < 8 || r.ldb < 8) return -2;
-    if (((uintptr_t)r.A & 15) || ((uintptr_t)r.B & 15) || ((uintptr_t)r.out & 3)) return -5;
-    r.tn = (r.No + BN - 1) / BN;
-    r.tile_begin = tiles;
-    tiles += r.tn * ((r.Mo + BM - 1) / BM);
-  }
-  p.ntiles = tiles;
-  p.kiters = p.K / BK;
-  const long long total = (long long)tiles * p.kiters;
-  if (total > (1ll << 30)) return -3;
-  p.total = (int)total;
-  p.per = (int)((total + max_wgs - 1) / max_wgs);
-  const long long l = (long long)p.kiters / gcd_i(p.kiters, p.per) * p.per;
-  p.lcm = l > (1ll << 30) ? (1 << 30) : (int)l;
-  return 0;
-}
-}  // namespace
-
-size_t tn_grouped_slab_floats(const TnGroupParams& p_in, int max_wgs) {
-  TnGroupParams p = p_in;
-  if (tn_group_plan(p, max_wgs)) return 0;
-  const int wgs = (p.total + p.per - 1) / p.per;
-  return (size_t)(p.ntiles + wgs) * BM * BN;  // upper bound on the number of segments
-}
-
-int launch_gemm_tn_grouped(TnGroupParams& p, int max_wgs, hipStream_t s) {
-  int rc = tn_group_plan(p, max_wgs);
-  if (rc) return rc;
-  if (!p.slab || ((uintptr_t)p.slab & 15)) return -5;
-  const int wgs = (p.total + p.per - 1) / p.per;
-  hipLaunchKernelGGL(gemm_tn_grouped_kernel, dim3(wgs), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(tn_grouped_reduce_kernel, dim3(p.ntiles, 4), dim3(256), 0, s, p);
-  return 0;
-}
 
 void gemm_set_nt_variant(int v) { g_nt_variant = v; }
 void gemm_set_nt_band(int band) { g_nt_band = band; }

@@ -371,37 +371,3 @@ def test_mse_loss_and_grad():
     d = dpred.float().view(B, n, ldp)
     _close(d[:, :, :D], pr.grad, 1e-2, 1e-6, "dpred")
     assert (d[:, :, D:] == 0).all() and (d[:, T:, :] == 0).all()
-
-
-@pytest.mark.parametrize("K,shapes,wgs", [
-    (640, [(800, 3072), (800, 2400), (800, 800), (3072, 800)], 512),   # FACT layer set, ragged 800
-    (128, [(40, 72)], 512),                                            # one partial tile, more WGs than units
-    (1920, [(136, 264), (128, 128)], 7),                               # few WGs: many tiles per workgroup
-    (3840, [(800, 800)], 512),                                         # many segments per tile
-])
-def test_gemm_tn_grouped(K, shapes, wgs):
-    """Grouped K-balanced wgrad (stream-K style split) against fp32 torch, accumulating into out."""
-    g = torch.Generator(device=DEV).manual_seed(5)
-    As, Bs, outs, refs = [], [], [], []
-    for (Mo, No) in shapes:
-        lda, ldb = (Mo + 7) // 8 * 8, (No + 7) // 8 * 8 + 8
-        A = torch.randn(K, lda, device=DEV, generator=g).to(torch.bfloat16)
-        B = torch.randn(K, ldb, device=DEV, generator=g).to(torch.bfloat16)
-        out = torch.randn(Mo, No, device=DEV, generator=g)
-        refs.append(out + A[:, :Mo].float().t() @ B[:, :No].float())
-        As.append(A); Bs.append(B); outs.append(out)
-    n = len(shapes)
-    vp, ci = C.c_void_p * n, C.c_int * n
-    args = (n, vp(*[a.data_ptr() for a in As]), ci(*[a.shape[1] for a in As]),
-            vp(*[b.data_ptr() for b in Bs]), ci(*[b.shape[1] for b in Bs]),
-            ci(*[s[0] for s in shapes]), ci(*[s[1] for s in shapes]),
-            vp(*[o.data_ptr() for o in outs]), ci(*[s[1] for s in shapes]), K, wgs)
-    lib = L.lib()
-    need = C.c_size_t(0)
-    L.check(lib.fact_op_gemm_tn_grouped(*args, None, 0, C.byref(need), None))
-    assert need.value > 0
-    scratch = torch.empty(need.value // 4, device=DEV)
-    L.check(lib.fact_op_gemm_tn_grouped(*args, L.ptr(scratch), need.value, None, L.cur_stream()))
-    torch.cuda.synchronize()
-    for o, r in zip(outs, refs):
-        assert (o - r).norm() / r.norm() < 5e-6

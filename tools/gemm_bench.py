@@ -78,36 +78,6 @@ for (M, N, K, epi) in ([] if os.environ.get("TN_ONLY") else SHAPES):
     lib.fact_debug_gemm_nt_band(8)
     print(line, flush=True)
 
-if os.environ.get("TN_GROUP"):
-    import ctypes as C
-    for K in map(int, os.environ.get("TN_GROUP_K", "5760,3840,1920").split(",")):
-        shapes = [(3072, 800), (800, 3072), (800, 800), (800, 2400)]
-        if os.environ.get("TN_GROUP_SHAPES"):
-            v = list(map(int, os.environ["TN_GROUP_SHAPES"].split(",")))
-            shapes = [(v[i], v[i + 1]) for i in range(0, len(v), 2)]
-        pad = int(os.environ.get("TN_PAD", "8"))
-        rp = lambda x: (x + pad - 1) // pad * pad
-        As = [torch.randn(K, rp(Mo), device=dev).to(torch.bfloat16) for Mo, _ in shapes]
-        Bs = [torch.randn(K, rp(No), device=dev).to(torch.bfloat16) for _, No in shapes]
-        outs = [torch.zeros(Mo, No, device=dev) for Mo, No in shapes]
-        n = len(shapes); vp, ci = C.c_void_p * n, C.c_int * n
-        for wgs in map(int, os.environ.get("TN_GROUP_WGS", "256,512,768,1024").split(",")):
-            args = (n, vp(*[a.data_ptr() for a in As]), ci(*[a.shape[1] for a in As]), vp(*[b.data_ptr() for b in Bs]),
-                    ci(*[b.shape[1] for b in Bs]), ci(*[s[0] for s in shapes]), ci(*[s[1] for s in shapes]),
-                    vp(*[o.data_ptr() for o in outs]), ci(*[s[1] for s in shapes]), K, wgs)
-            need = C.c_size_t(0)
-            L.check(lib.fact_op_gemm_tn_grouped(*args, None, 0, C.byref(need), None))
-            scratch = torch.empty(need.value // 4, device=dev)
-            f = lambda: L.check(lib.fact_op_gemm_tn_grouped(*args, L.ptr(scratch), need.value, None, L.cur_stream()))
-            for _ in range(3): f()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(20): f()
-            e1.record(); e1.synchronize()
-            us = e0.elapsed_time(e1) / 20 * 1e3
-            fl = sum(2.0 * K * a * b for a, b in shapes)
-            print("grouped layer wgrad K%d wgs%d: %.1f us %.0f TF (scratch %.0f MB)" % (K, wgs, us, fl / us / 1e6, need.value / 1e6), flush=True)
-    sys.exit(0)
 print("--- TN (wgrad) ---")
 TN_SHAPES = [tuple(map(int, os.environ["TN_SHAPE"].split(",")))] if os.environ.get("TN_SHAPE") else [(5760, 800, 3072), (5760, 3072, 800), (5760, 2400, 800), (5760, 800, 800), (1920, 3072, 800), (3840, 2400, 800)]
 for (K, Mo, No) in TN_SHAPES:
