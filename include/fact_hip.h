@@ -99,16 +99,17 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
 /* Replaces optimizer.apply_gradients (single_task_trainer.py:186-187) with Keras-Adam semantics
  * (epsilon outside the bias correction), optional clip_by_global_norm (:180-183; clip_norm <= 0
  * disables; enabling it synchronises the stream once). Zeroes the grad arena, advances the step
- * counter and refreshes the bf16 weight shadows. */
+ * counter and rewrites the bf16 weight shadows - one pass over p / m / v / g (36 bytes per parameter). */
 int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps, float clip_norm,
                    void* stream);
-/* Optimizer step fused INTO the backward pass (no gradient clipping): call fact_adam_begin before
- * fact_forward_backward; every gradient bucket is then updated (Keras Adam + grad zeroing + bf16
- * shadow refresh of that bucket) as soon as it is final - by the engine itself on an internal
- * optimizer stream when no gradient callback is registered (the HBM-bound update hides behind the
- * remaining MFMA/LDS-DMA-bound backward kernels and is joined before fact_forward_backward's work
- * completes on the caller's stream), or by the host calling fact_adam_bucket(bucket, comm_stream)
- * from its fact_grad_cb after that bucket's all-reduce.  Same arithmetic as fact_adam_step. */
+/* OPTIONAL: optimizer step inside the backward pass (no gradient clipping): call fact_adam_begin
+ * before fact_forward_backward; every gradient bucket is then updated (Keras Adam + grad zeroing +
+ * bf16 shadows of that bucket) as soon as it is final - by the engine itself on an internal optimizer
+ * stream when no gradient callback is registered (joined before fact_forward_backward's work completes
+ * on the caller's stream), or by the host calling fact_adam_bucket(bucket, comm_stream) from its
+ * fact_grad_cb after that bucket's all-reduce.  Same arithmetic as fact_adam_step.  On MI355X the
+ * HBM-bound update slows the concurrent GEMMs by more than it hides (11.5 vs 11.2 ms per step), so
+ * the host trainer's default is fact_adam_step after backward. */
 int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps);
 int fact_adam_bucket(FactHandle* h, int bucket, void* stream);
 int fact_num_buckets(FactHandle* h, int* n);
@@ -133,7 +134,12 @@ int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, i
 typedef void (*fact_grad_cb)(void* user, int bucket, size_t offset_floats, size_t count_floats);
 int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* comm_stream);
 
-/* Engine knobs: key "wgrad_tr" (1 = LDS transpose-read wgrad GEMM, 0 = explicit transposes). */
+/* Engine knobs (all default to 1; the 0 settings are the reference paths the tests compare against):
+ *   "wgrad_tr"       1 = wgrad GEMM builds its fragments with the LDS transpose read, 0 = explicit transposes
+ *   "wgrad_slab"     1 = split-K partials as plain stores + a streaming reduce, 0 = fp32 atomics
+ *   "side_stream"    1 = wgrad batches / the audio encoder run on the handle's second stream, 0 = one stream
+ *   "fuse_adam_cast" 1 = Adam writes the bf16 weight shadows itself, 0 = Adam, then a cast/transpose pass
+ * Unknown keys return an error. */
 int fact_set_option(FactHandle* h, const char* key, int value);
 
 /* ---- single-op entry points (used by the parity tests; same kernels as the model path) ---- */
