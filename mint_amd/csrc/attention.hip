@@ -613,19 +613,32 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_res_kernel(const AttnParams p
   res_load<G::DHP, G::DHP / 8, true>(Vimg, p.vrow + row_base, rows, wave, nw, lane);
 
   const int q0 = wave * 32;
+  const int b = bh / p.H, h = bh - b * p.H;
   bf16x8 Qf[2][G::KD], dOf[2][G::KD];
   float L2q[2], Dq[2];
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs) {
     const int q = q0 + qs * 16 + (lane & 15);
+    // D[q] = rowsum(dO o O) is computed here (no separate pass over dO and O): this lane holds 8 head
+    // columns of dO per 32-column slab, the 4 lanes of a row (g = 0..3) cover the slab
+    float part = 0.f;
 #pragma unroll
     for (int kd = 0; kd < G::KD; ++kd) {
       const size_t off = row_base + (size_t)q * G::DHP + kd * 32 + g * 8;
       Qf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.qrow + off);
       dOf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.dorow + off);
+      const int d0 = kd * 32 + g * 8;
+      if (q < p.n && d0 < DH) {
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(p.o + ((size_t)b * p.n + q) * p.ldo + h * DH + d0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += (float)dOf[qs][kd][j] * (float)ov[j];
+      }
     }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
     L2q[qs] = p.lse2[(size_t)bh * p.NP + q];
-    Dq[qs] = p.dsum[(size_t)bh * p.NP + q];
+    Dq[qs] = part;
+    if (g == 0) p.dsum[(size_t)bh * p.NP + q] = part;  // for the dK/dV kernel (0 on padded query rows)
   }
   f32x4 dQ[2][G::ND];
 #pragma unroll
@@ -680,7 +693,6 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_res_kernel(const AttnParams p
       for (int qs = 0; qs < 2; ++qs) dQ[qs][dt] = mfma16(ktf, dsb[qs], dQ[qs][dt]);
     }
   }
-  const int b = bh / p.H, h = bh - b * p.H;
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs) {
     const int t = q0 + qs * 16 + (lane & 15);
@@ -870,8 +882,9 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
 template <int DH>
 int bwd_t(const AttnParams& p, hipStream_t s) {
   const int total = p.B * p.H * p.NP;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel<DH>, dim3((total + 255) / 256), dim3(256), 0, s, p);
   const size_t lds1 = res_lds_bytes<DH>(p.n, 1), lds2 = res_lds_bytes<DH>(p.n, 2);
+  // the LDS-resident dQ kernel computes D = rowsum(dO o O) itself; only the tiled path needs the pass
+  if (!lds1) hipLaunchKernelGGL(attn_bwd_prep_kernel<DH>, dim3((total + 255) / 256), dim3(256), 0, s, p);
   const int nw = ((p.n + 31) & ~31) / 32;
   dim3 grid((p.n + 127) / 128, p.B * p.H);
   if (lds1) {
