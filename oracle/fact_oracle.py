@@ -18,13 +18,20 @@ the reference algorithm, one function per reference symbol, honouring the refere
   train_step          mint/ctl/single_task_trainer.py:141-196 (loss/R, summed grads, optional
                       clip_by_global_norm) + Keras Adam (epsilon outside the bias correction)
 
-PARITY UNPINNED: the reference itself cannot run here (TensorFlow/Keras/Orbit are absent and the
-model tests in the reference pin shapes only — fact_model_test.py:47-54, base_models_test.py:22-40),
-so there are no reference-produced numeric vectors for this path.  What pins this file instead:
-the reference's shape tests, the reference's only numeric KAT (learning_schedules_test.py:22-40,
-against mint_amd.learning_schedules), and an independent cross-check against torch.nn compositions
-(tests/test_oracle.py).  The committed fixtures under tests/golden/ are produced BY this oracle
-(tests/golden/make_golden.py) and guard against drift, not against the reference.
+PARITY PIN: the reference as shipped cannot run here (TensorFlow/Keras/Orbit are absent; its model tests
+pin shapes only - fact_model_test.py:47-54, base_models_test.py:22-40).  What does run is the reference's
+own MODEL CODE: tests/golden/make_reference_golden.py imports /root/reference/mint/core/*.py unchanged on
+top of a stand-in for the few TensorFlow/Keras primitives it calls (tests/golden/ref_shim: Dense,
+LayerNormalization, softmax, einsum, concat, reduce_mean ... on PyTorch-CPU float64; einops supplies
+Rearrange) and records FACTModel.call / .loss / .infer_auto_regressive and the autograd gradients of that
+loss.  tests/test_oracle_vs_reference.py holds this oracle to those vectors at 1e-12 (they agree to the last
+bit), and re-runs the reference code live where the checkout exists.  So the composition - layer order,
+pre-LN residuals, hidden**-0.5 scale, "(qkv h d)" split, tanh-GELU, [motion; audio] concat, loss slice, AR
+window shift / early break - is pinned on the reference; the primitives themselves (and Keras Adam, which
+the reference only instantiates) are restated from the Keras documentation and remain UNPINNED against a
+real TensorFlow build.  Further pins: the reference's only numeric KAT (learning_schedules_test.py:22-40,
+against mint_amd.learning_schedules) and an independent torch.nn cross-check (tests/test_oracle.py).
+tests/golden/tiny_fact_golden.npz is produced BY this oracle (make_golden.py) and guards against drift.
 
 Third-party arithmetic restated here (not under /root/reference): TensorFlow/Keras Dense,
 LayerNormalization, softmax, einsum, Adam (README.md:21 `pip install tensorflow`, unpinned, TF 2.4-2.6
