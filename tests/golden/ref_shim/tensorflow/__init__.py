@@ -37,6 +37,11 @@ class Tensor(torch.Tensor):
     def shape(self):
         return _Shape(super().shape)
 
+    def __rmul__(self, other):  # `python_list * tensor`, which TensorFlow converts like any other operand
+        if isinstance(other, (list, tuple)):
+            other = torch.as_tensor(other, dtype=torch.float64)
+        return (other * self.as_subclass(torch.Tensor)).as_subclass(Tensor)
+
 
 def convert_to_tensor(x, dtype=None):
     t = torch.as_tensor(x)
@@ -112,3 +117,77 @@ try:
     _eb._type2backend[torch.Tensor] = _tb
 except Exception:  # pragma: no cover - einops layout changed: fail at first use instead
     pass
+
+
+# ---- primitives used by mint/utils/inputs_util.py:fact_preprocessing and mint/core/learning_schedules.py ----
+def _set_shape(self, shp):
+    assert len(shp) == self.dim() and all(s is None or int(s) == int(d) for s, d in zip(shp, self.size())), \
+        "set_shape(%s) on a tensor of shape %s" % (list(shp), list(self.size()))
+
+
+Tensor.set_shape = _set_shape
+
+
+def pad(x, paddings):
+    flat = []
+    for lo, hi in reversed([list(p) for p in paddings]):
+        flat += [int(lo), int(hi)]
+    return torch.nn.functional.pad(_raw(x), flat).as_subclass(Tensor)
+
+
+def maximum(a, b):
+    if isinstance(a, torch.Tensor) or isinstance(b, torch.Tensor):
+        return torch.maximum(torch.as_tensor(_raw(a)), torch.as_tensor(_raw(b))).as_subclass(Tensor)
+    return max(a, b)
+
+
+def cast(x, dtype):
+    return torch.as_tensor(_raw(x)).to(dtype).as_subclass(Tensor)
+
+
+def greater_equal(a, b):
+    return torch.as_tensor(_raw(a)) >= torch.as_tensor(b)
+
+
+def where(cond, a, b):
+    return torch.where(cond, torch.as_tensor(a), torch.as_tensor(b))
+
+
+def reduce_max(x, axis=None):
+    return torch.as_tensor(x).max()
+
+
+def reduce_sum(x, axis=None, name=None):
+    return torch.as_tensor(_raw(x)).sum().as_subclass(Tensor)
+
+
+def one_hot(index, depth):
+    return torch.nn.functional.one_hot(torch.as_tensor(index).long(), depth).to(torch.float64).as_subclass(Tensor)
+
+
+class name_scope:  # noqa: N801
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        return self.name
+
+    def __exit__(self, *a):
+        return False
+
+
+random = types.ModuleType("tensorflow.random")
+random.forced = None  # tests set this to make the reference's random window start reproducible
+
+
+def _uniform(shape, minval=0, maxval=None, dtype=None):
+    assert list(shape) == [], "shim: scalar tf.random.uniform only"
+    if random.forced is not None:
+        v = int(random.forced)
+        assert minval <= v < int(maxval)
+        return v
+    return int(torch.randint(int(minval), int(maxval), ()).item())
+
+
+random.uniform = _uniform
+sys.modules["tensorflow.random"] = random

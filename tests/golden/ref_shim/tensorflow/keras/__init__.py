@@ -52,3 +52,14 @@ class Metric:
 
 
 metrics.Metric = Metric
+
+optimizers = types.ModuleType("tensorflow.keras.optimizers")
+optimizers.schedules = types.ModuleType("tensorflow.keras.optimizers.schedules")
+
+
+class LearningRateSchedule:
+    def __init__(self, *a, **k):
+        pass
+
+
+optimizers.schedules.LearningRateSchedule = LearningRateSchedule

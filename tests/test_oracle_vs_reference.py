@@ -100,3 +100,58 @@ def test_reference_width_mismatch_error_is_the_one_we_mirror():
     m = model_builder.build(G.proto_from_cfg(model_pb2, cfg), True)
     with pytest.raises(ValueError, match="should be the same"):
         m({"motion_input": tf.constant(torch.zeros(1, 32, 225)), "audio_input": tf.constant(torch.zeros(1, 64, 35))})
+
+
+# ---- the callers either side of the model, reference code run live under the same shim -------
+_HAS_REF = os.path.isdir(os.path.join(G.REF, "mint", "core"))
+
+
+@pytest.mark.skipif(not _HAS_REF, reason="reference checkout not present")
+@pytest.mark.parametrize("warmup", [False, True])
+def test_manual_stepping_matches_reference_class(warmup):
+    """mint/core/learning_schedules.py:19-67 (the schedule fact_v5_deeper_t10_cm12.config selects) against
+    mint_amd.learning_schedules.ManualStepping at boundaries, between them and far beyond."""
+    G.import_reference()
+    from mint.core import learning_schedules as ref_ls
+    from mint_amd import learning_schedules as our_ls
+    bounds, rates = [100, 1500, 4000], [1e-4, 1e-5, 1e-6, 1e-7]
+    ref = ref_ls.ManualStepping(list(bounds), list(rates), warmup)
+    ours = our_ls.ManualStepping(list(bounds), list(rates), warmup)
+    for step in [0, 1, 37, 99, 100, 101, 1499, 1500, 3999, 4000, 4001, 10 ** 6]:
+        assert float(ours(step)) == pytest.approx(float(ref(step)), rel=1e-12, abs=0.0), step
+
+
+@pytest.mark.skipif(not _HAS_REF, reason="reference checkout not present")
+@pytest.mark.parametrize("is_training,start", [(True, 0), (True, 17), (True, 60), (False, 0)])
+def test_fact_preprocessing_matches_reference_function(is_training, start):
+    """mint/utils/inputs_util.py:59-107 run under the shim (its random window start forced to `start`)
+    against mint_amd.inputs_util.fact_preprocessing on the same example: 6-column left pad, window slices,
+    target shift, whole audio track in eval."""
+    G.import_reference()
+    import tensorflow as tf
+    from mint.utils import inputs_util as ref_iu
+    from mint_amd import inputs_util as our_iu
+    rs = np.random.RandomState(5)
+    motion = rs.randn(200, 219).astype(np.float32)
+    audio = rs.randn(200, 35).astype(np.float32)
+    params = {"motion": {"input_length": 120, "target_length": 20, "target_shift": 120, "feature_dim": 219},
+              "audio": {"input_length": 140, "target_length": 0, "target_shift": 0, "feature_dim": 35}}
+    # window = max(120, 120 + 20, 140) = 140 -> start in [0, 61)
+    tf.random.forced = start
+    try:
+        ref = ref_iu.fact_preprocessing({"motion_sequence": tf.constant(motion), "audio_sequence": tf.constant(audio)},
+                                        params, is_training)
+    finally:
+        tf.random.forced = None
+
+    class Forced:
+        def randint(self, lo, hi):
+            assert lo <= start < hi
+            return start
+    ours = our_iu.fact_preprocessing({"motion_sequence": motion, "audio_sequence": audio}, params, is_training,
+                                     rng=Forced())
+    assert set(ours.keys()) == set(ref.keys())
+    for k in ref:
+        r = np.asarray(ref[k].as_subclass(torch.Tensor), dtype=np.float64)
+        assert ours[k].shape == r.shape, k
+        assert np.array_equal(np.asarray(ours[k], dtype=np.float64), r), k
