@@ -137,8 +137,6 @@ struct FactHandle {
   float *dxm = nullptr, *dxa = nullptr;  // encoder gradients after the split
   bf16_t *dxm16 = nullptr, *dxa16 = nullptr;
   bf16_t* dh = nullptr;      // [Mc][d]
-  bf16_t* dpre = nullptr;    // [Mc][ffmax]
-  bf16_t* dqkv = nullptr;    // [Mc][3d]
   bf16_t* dorow = nullptr;
   float* dsum = nullptr;
   bf16_t *tA = nullptr, *tB = nullptr;  // transposed operands for the non-tr wgrad path
@@ -165,7 +163,7 @@ struct FactHandle {
   size_t ev_i = 0;
   // Backward scratch that the wgrad stream reads is double-buffered (layer parity) so the dgrad chain
   // only ever waits for the wgrad GEMMs of TWO layers ago, never for the ones just enqueued.
-  bf16_t *dpre_pp[2] = {nullptr, nullptr}, *dqkv_pp[2] = {nullptr, nullptr};
+  bf16_t *dpre_pp[2] = {nullptr, nullptr}, *dqkv_pp[2] = {nullptr, nullptr};  // [Mc][ff pitch], [Mc][3d pitch]
   bf16_t *xmid_pp[2] = {nullptr, nullptr};  // bf16 gradient at x_mid
   bf16_t *xb_pp[2] = {nullptr, nullptr};    // bf16 gradient at the layer boundary (output of layer parity q)
   hipEvent_t ev_batch[2] = {nullptr, nullptr};  // wgrad batch of the last layer of parity q finished
@@ -381,8 +379,6 @@ void layout_work(FactHandle* h, Bump& b) {
       h->dpre_pp[q] = b.take<bf16_t>(Mc * ffmax);
       h->dqkv_pp[q] = b.take<bf16_t>(Mc * h->cross.qp);
     }
-    h->dpre = h->dpre_pp[0];
-    h->dqkv = h->dqkv_pp[0];
     for (int q = 0; q < 2; ++q) {
       h->xmid_pp[q] = b.take<bf16_t>(Mc * dp);
       h->xb_pp[q] = b.take<bf16_t>(Mc * dp);
