@@ -890,7 +890,6 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
     if (rc2) return rc2;
   }
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&h->opt, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
   h->ev.resize(1024);  // ~170 records per train step: a stored handle is never re-recorded before its use
   for (hipEvent_t& e : h->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1036,6 +1035,8 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   // (the four encoder layers used to take 1.5 ms of a 10.4 ms step).
   hipStream_t ms = (h->use_side && h->aux) ? h->aux : s;
   if (ms != s) stream_after(h, s, ms);
+  // (audio first: its big-tile GEMMs need whole CUs; enqueued second they wait ~0.5 ms behind the motion
+  //  chain's one-workgroup-per-CU kernels - rocprofv3 timeline, tools/tail_view.py)
   g16 = h->dxa16;
   for (int l = au.L - 1; l >= 0; --l) CHK(layer_backward(h, au, l, B, h->dxa, g16, s, h->bw[0]));
   CHK(embed_backward(h, au, B, h->dxa, g16, s, h->bw[0]));
@@ -1094,6 +1095,8 @@ int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps
   h->adam.b2 = beta2;
   h->adam.eps = eps;
   h->adam.gscale = 1.0f;
+  // created on first use (the default trainer never needs it)
+  if (!h->opt) HIPCHK(hipStreamCreateWithFlags(&h->opt, hipStreamNonBlocking));
   h->adam_pending = true;
   return 0;
 }
