@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-phase timing to stderr")
     ap.add_argument("--side-stream", type=int, default=1, help="0 = single-stream engine (A/B knob)")
-    ap.add_argument("--fuse-optimizer", type=int, default=0, help="1 = per-bucket Adam inside backward (A/B knob)")
+    ap.add_argument("--fuse-optimizer", type=int, default=1, help="0 = Adam as a separate pass after backward (A/B knob)")
     return ap.parse_args()
 
 

@@ -786,9 +786,17 @@ int notify_grads(FactHandle* h, hipStream_t s) {
     if (side_of(h, s) != s) stream_after(h, h->side, h->cb_stream);
     h->cb(h->cb_user, b, k.off, k.cnt);
   } else if (h->adam_pending) {
+    // In-backward optimizer.  Updating every bucket the moment it is final slows the dense cross-modal
+    // backward by more than it hides, so the head + cross-modal buckets are held back and
+    // updated together when the LAST cross-modal bucket is final: the HBM-bound update then runs beside
+    // the two small encoder stacks' backward, which leaves most of the chip idle.  The encoder buckets
+    // follow as they complete.
+    const int last_cross = h->cross.L;  // bucket 0 = head, 1..L = cross layers L-1..0
+    if (b < last_cross) return 0;
+    const int first = (b == last_cross) ? 0 : b;
     stream_after(h, s, h->opt);
     if (side_of(h, s) != s) stream_after(h, h->side, h->opt);
-    CHK(adam_bucket(h, b, h->opt));
+    for (int i = first; i <= b; ++i) CHK(adam_bucket(h, i, h->opt));
   }
   return 0;
 }

@@ -121,7 +121,7 @@ class SingleTaskTrainer:
 
     def __init__(self, train_dataset, label_key, model, loss_fn=None, optimizer=None, metrics=None,
                  trainer_options=None, summary_fn=None, grad_clip_norm=0.0, overlap_grad_allreduce=None,
-                 fuse_optimizer=False):
+                 fuse_optimizer=True):
         self.train_dataset = train_dataset
         self.label_key = label_key
         self.model = model
@@ -146,10 +146,12 @@ class SingleTaskTrainer:
             overlap_grad_allreduce = (self.num_replicas_in_sync > 1 and hasattr(model, "set_grad_callback")
                                       and dist.get_backend() == "nccl")
         self._overlap = bool(overlap_grad_allreduce)  # reducer is created lazily (model builds on 1st batch)
-        # Optional: per-bucket optimizer step INSIDE backward (engine API, no global-norm clipping).
-        # Off by default: on MI355X the HBM-bound Adam pass slows the concurrent GEMMs by more than it
-        # hides (measured 11.51 vs 11.22 ms/step at B = 16); one fused Adam + shadow pass after the
-        # (overlapped) gradient all-reduce is faster.
+        # Optimizer step inside backward (engine API, no global-norm clipping), single replica only: the
+        # engine holds the head + cross-modal buckets back until the cross-modal backward is done and
+        # updates them beside the two small encoder stacks' backward (10.27 vs 10.35 ms/step at B = 16).
+        # Updating every bucket as soon as it is final - which is what the data-parallel reducer would
+        # have to do behind each all-reduce - slows the dense backward by more than it hides
+        # (11.51 vs 11.22 ms), so with more than one replica Adam is one pass after the all-reduce.
         self._fuse = bool(fuse_optimizer) and hasattr(model, "begin_fused_adam") and not (grad_clip_norm > 0.)
 
     def train_loop_begin(self):
@@ -173,13 +175,11 @@ class SingleTaskTrainer:
             self.model.ensure_built(inputs)
         if self._overlap and self._reducer is None:
             self._reducer = OverlappedGradReducer(self.model)
-        # fused path: single replica (engine updates buckets itself) or overlapped DP (reducer does)
-        fused = self._fuse and (R == 1 or self._reducer is not None)
+        # fused path: single replica without a gradient callback (the engine updates the buckets itself)
+        fused = self._fuse and R == 1 and self._reducer is None
         lr = None
         if fused:
             lr = self.optimizer.begin_fused(self.model)
-            if self._reducer is not None:
-                self._reducer.fused_adam = True
         elif self._reducer is not None:
             self._reducer.fused_adam = False
         raw_loss = self.model.forward_backward(inputs, target, loss_scale=1.0 / R)
