@@ -102,14 +102,14 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
  * counter and rewrites the bf16 weight shadows - one pass over p / m / v / g (36 bytes per parameter). */
 int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps, float clip_norm,
                    void* stream);
-/* OPTIONAL: optimizer step inside the backward pass (no gradient clipping): call fact_adam_begin
- * before fact_forward_backward; every gradient bucket is then updated (Keras Adam + grad zeroing +
- * bf16 shadows of that bucket) as soon as it is final - by the engine itself on an internal optimizer
- * stream when no gradient callback is registered (joined before fact_forward_backward's work completes
- * on the caller's stream), or by the host calling fact_adam_bucket(bucket, comm_stream) from its
- * fact_grad_cb after that bucket's all-reduce.  Same arithmetic as fact_adam_step.  On MI355X the
- * HBM-bound update slows the concurrent GEMMs by more than it hides (11.5 vs 11.2 ms per step), so
- * the host trainer's default is fact_adam_step after backward. */
+/* Optimizer step inside the backward pass (no gradient clipping): call fact_adam_begin before
+ * fact_forward_backward.  Without a gradient callback the engine updates the buckets itself on an internal
+ * optimizer stream (Keras Adam + grad zeroing + bf16 shadows; joined before fact_forward_backward's work
+ * completes on the caller's stream): the head and cross-modal buckets together once the last of them is
+ * final - i.e. beside the backward of the two small encoder stacks, not beside the dense cross-modal
+ * backward, which an HBM-bound update slows by more than it hides - then the encoder buckets.  With a
+ * callback the host may call fact_adam_bucket(bucket, comm_stream) from its fact_grad_cb after that
+ * bucket's all-reduce.  Same arithmetic as fact_adam_step. */
 int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps);
 int fact_adam_bucket(FactHandle* h, int bucket, void* stream);
 int fact_num_buckets(FactHandle* h, int* n);
