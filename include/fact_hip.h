@@ -112,6 +112,8 @@ int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps,
  * bucket's all-reduce.  Same arithmetic as fact_adam_step. */
 int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps);
 int fact_adam_bucket(FactHandle* h, int bucket, void* stream);
+/* Disarm a fact_adam_begin whose fact_forward_backward never ran (host-side error): step counter restored. */
+int fact_adam_cancel(FactHandle* h);
 int fact_num_buckets(FactHandle* h, int* n);
 int fact_get_step(FactHandle* h, int64_t* step);
 int fact_set_step(FactHandle* h, int64_t step);
@@ -150,6 +152,13 @@ int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int
 /* C(MoxNo) += A^T B with A [K][Mo], B [K][No] bf16 (wgrad form), f32 atomic accumulate. */
 int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int No, int K,
                     float* out, int ldo, int splitk, int use_tr, void* scratch, void* stream);
+/* Grouped whole-K weight-gradient GEMM (one launch for the 1..4 wgrads of a transformer layer, 160x256 tiles,
+ * no split-K): out_i[Mo_i][No_i] += A_i^T B_i with A_i bf16 [K][lda_i], B_i bf16 [K][ldb_i]; trans[i] = 1
+ * stores out_i as [No_i][Mo_i].  K % 32 == 0, Mo / No / ldo % 4 == 0.  Replaces the tape's Dense-kernel
+ * gradients (single_task_trainer.py:175-178 through base_models.py:51-53,68-69). */
+int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                          float* const* out, const int* ldo, const int* Mo, const int* No, const int* trans, int K,
+                          void* stream);
 int fact_op_ln_fwd(const float* x, const float* gamma, const float* beta, void* h, float* mean,
                    float* rstd, int M, int C, float eps, void* stream);
 int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
@@ -174,6 +183,7 @@ int fact_debug_force_generic_gemm(int on);
 /* Test knob: 1 = use the tiled (streaming) attention kernels even when the LDS-resident ones fit. */
 int fact_debug_attn_force_tiled(int on);
 /* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 6 / 7 = big-tile 288x256 / 256x256). */
+int fact_debug_gemm_big_impl(int v); /* 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel */
 int fact_debug_gemm_nt_variant(int v);
 /* Test/bench knob: NT GEMM tile band height (tile order inside an XCD; 1 = row-major, default 8). */
 int fact_debug_gemm_nt_band(int band);

@@ -54,6 +54,7 @@ SIGNATURES = {
     "fact_adam_step": (_i, [_vp, _f, _f, _f, _f, _f, _vp]),
     "fact_adam_begin": (_i, [_vp, _f, _f, _f, _f]),
     "fact_adam_bucket": (_i, [_vp, _i, _vp]),
+    "fact_adam_cancel": (_i, [_vp]),
     "fact_num_buckets": (_i, [_vp, C.POINTER(_i)]),
     "fact_get_step": (_i, [_vp, C.POINTER(C.c_int64)]),
     "fact_set_step": (_i, [_vp, C.c_int64]),
@@ -63,6 +64,8 @@ SIGNATURES = {
     "fact_op_gemm_nt": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i,
                              _vp, _i, _vp]),
     "fact_op_gemm_tn": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "fact_op_gemm_tn_group": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp),
+                                   C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
     "fact_op_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "fact_op_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fact_op_attention_scratch": (_sz, [_i, _i, _i, _i]),
@@ -73,6 +76,7 @@ SIGNATURES = {
     "fact_probe_tr": (_i, [_vp, _i, _vp, _vp, _vp]),
     "fact_debug_force_generic_gemm": (_i, [_i]),
     "fact_debug_gemm_nt_variant": (_i, [_i]),
+    "fact_debug_gemm_big_impl": (_i, [_i]),
     "fact_debug_gemm_nt_band": (_i, [_i]),
     "fact_debug_ln_bwd": (_i, [_i, _i]),
     "fact_debug_attn_force_tiled": (_i, [_i]),

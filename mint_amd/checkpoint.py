@@ -1,5 +1,9 @@
 """Checkpoint cadence of trainer.py:168-173 (tf.train.CheckpointManager: every `checkpoint_interval`
-steps, keep `max_to_keep`) on the engine's state (fp32 params, Adam m/v, step) — row f3/f4."""
+steps, keep `max_to_keep`) on the engine's state (fp32 params, Adam m/v, step) — row f3/f4.
+
+The on-disk format is this repo's own (`ckpt-<step>.pt`: flat fp32 arenas + the variable-name table);
+it is NOT a TensorFlow object-graph checkpoint.  `optimizer=None` mirrors the evaluator's
+Checkpoint(model, global_step) (evaluator.py:64-67)."""
 import glob
 import os
 import re
@@ -27,11 +31,13 @@ class CheckpointManager:
         return paths[-1][1] if paths else None
 
     def save(self, step=None, check_interval=True):
-        step = self.optimizer.iterations if step is None else step
+        if step is None:
+            step = self.optimizer.iterations if self.optimizer is not None else int(self.model.global_step)
         if check_interval and step % self.checkpoint_interval != 0:
             return None
         state = self.model.state_dict()
-        state["optimizer_iterations"] = int(self.optimizer.iterations)
+        state["optimizer_iterations"] = int(self.optimizer.iterations if self.optimizer is not None
+                                            else self.model.global_step)
         path = os.path.join(self.directory, "ckpt-%d.pt" % step)
         torch.save(state, path + ".tmp")
         os.replace(path + ".tmp", path)
@@ -43,7 +49,11 @@ class CheckpointManager:
         path = self.latest_checkpoint
         if path is None:
             return None
-        state = torch.load(path, map_location="cpu", weights_only=False)
+        # the state holds only tensors, ints and lists of str: no pickled code is ever executed
+        state = torch.load(path, map_location="cpu", weights_only=True)
+        # like tf.train.Checkpoint the restore may precede variable creation (the reference restores
+        # before the first call, trainer.py:168-173): the model applies it when the engine is built
         self.model.load_state_dict(state)
-        self.optimizer.iterations = int(state.get("optimizer_iterations", state.get("global_step", 0)))
+        if self.optimizer is not None:
+            self.optimizer.iterations = int(state.get("optimizer_iterations", state.get("global_step", 0)))
         return path

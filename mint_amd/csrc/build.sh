@@ -7,12 +7,12 @@ mkdir -p "$OUT" "$OUT/obj"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
 pids=()
-for f in gemm rowops attention engine probe; do
+for f in gemm gemm_big rowops attention engine probe; do
   if [ ! -f "$OUT/obj/$f.o" ] || [ "$f.hip" -nt "$OUT/obj/$f.o" ] || [ -n "$(find . ../../include -name '*.h' -newer "$OUT/obj/$f.o" 2>/dev/null)" ]; then
     $HIPCC $FLAGS -c "$f.hip" -o "$OUT/obj/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libfact_hip.so" "$OUT"/obj/gemm.o "$OUT"/obj/rowops.o "$OUT"/obj/attention.o "$OUT"/obj/engine.o "$OUT"/obj/probe.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libfact_hip.so" "$OUT"/obj/gemm.o "$OUT"/obj/gemm_big.o "$OUT"/obj/rowops.o "$OUT"/obj/attention.o "$OUT"/obj/engine.o "$OUT"/obj/probe.o
 echo "built $OUT/libfact_hip.so"

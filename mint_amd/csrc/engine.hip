@@ -169,6 +169,7 @@ struct FactHandle {
   int64_t step = 0;
   int wgrad_tr = 1;
   int wgrad_slab = 1;
+  int wgrad_big = 1;  // whole-K grouped big-tile wgrad launch per layer (gemm_big.hip)
   float* slab = nullptr;  // split-K partial slabs of the wgrad GEMM running on the side stream
   // second stream: wgrad GEMMs run beside the dgrad chain, the audio encoder beside the motion encoder
   int use_side = 1;
@@ -586,6 +587,30 @@ int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int 
   return launch_gemm_nt(EPI_ATOMIC_F32, p, s);
 }
 
+// The four weight gradients of one transformer layer as ONE grouped whole-K launch (gemm_big.hip): 160x256
+// tiles, the d-wide operand on the 160-tiled side (d = 800 -> 5 tiles exactly); dW2 = g^T dY is computed as
+// (dY^T g) and stored transposed.  Returns 1 when the shape is not eligible (caller takes the per-GEMM path).
+int wgrad_layer_group(FactHandle* h, const Stack& st, const LayerP& p, const LayerA& a, const bf16_t* xin16,
+                      const bf16_t* dpre, const bf16_t* xmid16, const bf16_t* dqkv, int M, hipStream_t s) {
+  const int d = st.d, ff = st.ff;
+  if (!h->wgrad_big || !h->wgrad_tr || (M & 31) || M < 512 || (d & 3) || (ff & 3) || d < 160) return 1;
+  TnGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = 4;
+  g.K = M;
+  auto set = [&](int i, const bf16_t* A, int lda, int Mo, const bf16_t* B, int ldb, int No, float* out, int ldo,
+                 int trans) {
+    TnProblem& q = g.p[i];
+    q.A = A; q.lda = lda; q.M = Mo; q.B = B; q.ldb = ldb; q.N = No; q.out = out; q.ldo = ldo; q.trans_out = trans;
+  };
+  set(0, xin16, st.dp, d, a.g, st.fp, ff, G(h, p.w2.w), d, 1);          // dW2[ff][d]  = g^T dY
+  set(1, a.h2, st.dp, d, dpre, st.fp, ff, G(h, p.w1.w), ff, 0);         // dW1[d][ff]  = LN2(x)^T dpre
+  set(2, a.a, st.dp, d, xmid16, st.dp, d, G(h, p.wo.w), d, 0);          // dWo[d][d]   = attn^T dx_mid
+  set(3, a.h1, st.dp, d, dqkv, st.qp, 3 * d, G(h, p.wqkv.w), 3 * d, 0); // dWqkv[d][3d] = LN1(x)^T dqkv
+  CHK(launch_big_tn_group(g, s));
+  return 0;
+}
+
 void heads_ep(EpiParams& ep, const Stack& st, bf16_t* const* row, int nwhich) {
   for (int w = 0; w < 3; ++w) ep.hrow[w] = (w < nwhich) ? row[w] : nullptr;
   ep.n_tok = st.n;
@@ -709,11 +734,17 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   }
   // ---- the layer's weight gradients: one batch on the side stream
   if (two) stream_after(h, s, w);  // xin16, dpre, xmid16, dqkv are all final
-  CHK(wgrad(h, a.g, fp, ff, xin16, dp, d, M, G(h, p.w2.w), d, w, slab));
-  CHK(wgrad(h, a.h2, dp, d, dpre, fp, ff, M, G(h, p.w1.w), ff, w, slab));
+  {
+    const int rc = wgrad_layer_group(h, st, p, a, xin16, dpre, xmid16, dqkv, M, w);
+    if (rc < 0) return rc;
+    if (rc > 0) {
+      CHK(wgrad(h, a.g, fp, ff, xin16, dp, d, M, G(h, p.w2.w), d, w, slab));
+      CHK(wgrad(h, a.h2, dp, d, dpre, fp, ff, M, G(h, p.w1.w), ff, w, slab));
+      CHK(wgrad(h, a.a, dp, d, xmid16, dp, d, M, G(h, p.wo.w), d, w, slab));
+      CHK(wgrad(h, a.h1, dp, d, dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w, slab));
+    }
+  }
   CHK(launch_colsum_bf16(dpre, fp, G(h, p.b1), M, ff, ff, w));
-  CHK(wgrad(h, a.a, dp, d, xmid16, dp, d, M, G(h, p.wo.w), d, w, slab));
-  CHK(wgrad(h, a.h1, dp, d, dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w, slab));
   if (two) sc.ev_batch[q] = stream_mark(h, w);
   {
     GemmParams g = gp(dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
@@ -972,6 +1003,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     h->wgrad_slab = value;
     return 0;
   }
+  if (!strcmp(key, "wgrad_big")) {
+    h->wgrad_big = value;
+    return 0;
+  }
   if (!strcmp(key, "side_stream")) {
     h->use_side = value;
     return 0;
@@ -1118,6 +1153,15 @@ int fact_adam_bucket(FactHandle* h, int bucket, void* stream) {
   return 0;
 }
 
+int fact_adam_cancel(FactHandle* h) {
+  if (!h) return fail(-1, "null handle");
+  if (h->adam_pending) {
+    h->adam_pending = false;
+    h->step -= 1;
+  }
+  return 0;
+}
+
 int fact_num_buckets(FactHandle* h, int* n) {
   if (!h || !n) return fail(-1, "null argument");
   *n = (int)h->buckets.size();
@@ -1218,6 +1262,29 @@ int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int 
   GemmParams p = gp(tA, ldk, tB, ldk, Mo, No, ldk);
   p.splitk = splitk; p.ep.out0 = out; p.ep.ldo0 = ldo;
   CHK(launch_gemm_nt(EPI_ATOMIC_F32, p, s));
+  return 0;
+}
+
+/* Test/bench driver of the grouped whole-K TN kernel (gemm_big.hip): n problems out_i (+)= A_i^T B_i over a
+ * shared K; arrays of n entries; trans[i] = 1 stores out_i as [N][M]. */
+int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                          float* const* out, const int* ldo, const int* Mo, const int* No, const int* trans, int K,
+                          void* stream) {
+  if (n < 1 || n > TN_GROUP_MAX) return fail(-1, "1..4 problems");
+  TnGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  g.K = K;
+  for (int i = 0; i < n; ++i) {
+    TnProblem& q = g.p[i];
+    q.A = (const bf16_t*)A[i]; q.lda = lda[i]; q.B = (const bf16_t*)B[i]; q.ldb = ldb[i];
+    q.out = out[i]; q.ldo = ldo[i]; q.M = Mo[i]; q.N = No[i]; q.trans_out = trans[i];
+  }
+  CHK(launch_big_tn_group(g, (hipStream_t)stream));
+  return 0;
+}
+int fact_debug_gemm_big_impl(int v) {
+  gemm_set_big_impl(v);
   return 0;
 }
 

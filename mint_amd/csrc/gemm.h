@@ -38,6 +38,7 @@ struct EpiParams {
   float alpha;
   size_t slab_stride;  // EPI_F32_SLAB: floats between consecutive k-split slabs
   int z;               // (device) k-split index of this block, filled in by the kernel
+  unsigned mg_hid, mg_dh, mg_ntok;  // EPI_HEADS in the big-tile kernels: 2^32 / d + 1 (filled by the launcher)
 };
 
 struct GemmParams {
@@ -52,8 +53,35 @@ struct GemmParams {
   EpiParams ep;
 };
 
+// ---- big-tile family (gemm_big.hip): one 8-wave workgroup per CU, 4-deep LDS-DMA ring -------------------
+enum BigCfgId : int { BIG_288x256 = 0, BIG_256x256 = 1, BIG_256x160 = 2, BIG_160x256 = 3 };
+int big_tile_dims(int cfg, int* bm, int* bn);
+// NT GEMM on a given tile config (K % 32 == 0, splitk == 1); fused epilogues as above.
+int launch_big_nt(int cfg, int epi, const GemmParams& p, hipStream_t stream);
+
+// Grouped whole-K TN GEMM (weight gradients of one layer in one launch, 160x256 tiles):
+//   out[m][n] (+)= sum_k A[k*lda + m] * B[k*ldb + n]           (trans_out = 0, out row pitch ldo >= N)
+//   out[n][m] (+)= ...                                          (trans_out = 1, out row pitch ldo >= M)
+constexpr int TN_GROUP_MAX = 4;
+struct TnProblem {
+  const bf16_t* A;
+  const bf16_t* B;
+  float* out;
+  int lda, ldb, ldo;
+  int M, N;        // A columns (the 160-tiled side), B columns (the 256-tiled side)
+  int trans_out;
+  int tiles_m, tile_begin;  // filled by the launcher
+};
+struct TnGroup {
+  TnProblem p[TN_GROUP_MAX];
+  int n;
+  int K;
+};
+int launch_big_tn_group(TnGroup g, hipStream_t stream);
+
 // Launchers. Return 0 on success, negative on invalid arguments.
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);
 int launch_gemm_tn(int epi, const GemmParams& p, hipStream_t stream);
-void gemm_set_nt_variant(int v);  // 0 auto, 1 = 128x128 kernel, 6 / 7 = big-tile 288x256 / 256x256
+void gemm_set_nt_variant(int v);  // 0 auto, 1 = 128x128, 6 / 7 = round-1 big tile, 10 / 11 / 12 = gemm_big.hip configs
+void gemm_set_big_impl(int v);    // auto mode: 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel
 void gemm_set_nt_band(int band);   // NT tile band height (1 = row-major)

@@ -13,6 +13,8 @@
 // with 8/16-byte vector accesses.
 #include "gemm.h"
 
+#include <cmath>
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -96,7 +98,9 @@ DEVINL void epilogue_store(const EpiParams& ep, int M, int N, int row, int col0,
     const int d = rem - h * ep.dh;
     const int b = row / ep.n_tok;
     const int t = row - b * ep.n_tok;
-    bf16_t* hr = ep.hrow[which];
+    // three-way select on scalar pointers: indexing the by-value kernarg array with a per-lane value
+    // makes hipcc spill the whole EpiParams to scratch (168-344 B/lane in round 1)
+    bf16_t* hr = (which == 0) ? ep.hrow[0] : (which == 1) ? ep.hrow[1] : ep.hrow[2];
     if (hr) {
       bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
       *reinterpret_cast<bf16x4*>(hr + ((size_t)(b * ep.heads + h) * ep.n_pad + t) * ep.dhp + d) = pk;
@@ -860,12 +864,29 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(const GemmParams p
   run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, bc.z);
 }
 
-int g_nt_band = 8;  // tile band height of the NT kernels (bench knob; measured: 8 >= 4 > row-major)
-int g_nt_variant = 0;  // 0 auto, 1 = 128x128 kernel, 6 / 7 = big-tile kernel 288x256 / 256x256 (bench/test knob)
+int g_nt_band = 8;  // tile band height of the 128x128 NT kernel (bench knob; measured: 8 >= 4 > row-major)
+// 0 auto; 1 = 128x128 kernel; 6 / 7 = round-1 big-tile kernel 288x256 / 256x256 (gemm_nt_big_kernel);
+// 10 / 11 / 12 = big-tile family of gemm_big.hip at 288x256 / 256x256 / 256x160 (bench/test knob)
+int g_nt_variant = 0;
+int g_big_impl = 1;  // auto mode: 1 = gemm_big.hip family, 0 = round-1 big kernel (A/B knob)
+
+template <int EPI>
+constexpr bool kBigEpi = (EPI == EPI_BF16 || EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_RESID ||
+                          EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD || EPI == EPI_HEADS || EPI == EPI_F32_BF16);
+
+// tile band (in m-tiles) that makes the ~tiles/8 tiles one XCD owns a near-square patch in bytes
+int band_for(int tiles, int tm, int bm, int bn) {
+  const double per_xcd = tiles / 8.0;
+  int band = (int)(std::sqrt(per_xcd * bn / bm) + 0.5);
+  if (band < 1) band = 1;
+  if (band > tm) band = tm;
+  return band;
+}
 
 template <int EPI>
 int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
+  const int user_band = p.band;
   if (p.band == 0) p.band = g_nt_band;
   const int tn = (p.N + BN - 1) / BN;
   const int tiles128 = tn * ((p.M + 127) / 128);
@@ -875,24 +896,37 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
   }
   int variant = g_nt_variant;
   if (p.splitk > 1) variant = 1;
-  else if (variant == 0) variant = 1;  // 128x128 kernel unless the big-tile rule below takes the shape
-  if constexpr (EPI != EPI_ATOMIC_F32) {
-    // Big-tile kernel (one 288x256 or 256x256 workgroup per CU): taken when its rounds of 256
-    // workgroups are well filled, counting tile padding: useful outputs / (rounds * 256 * tile area)
-    // >= 0.6 - e.g. M = 5760, N = 3072 -> 20 x 12 = 240 tiles of 288 x 256 (0.94).  A GEMM that leaves a
-    // round mostly empty (276 tiles) or whose N is far below a tile (N = 800) stays on the 128x128 kernel.
-    const int tnb = (p.N + 255) / 256;
-    const int t9 = tnb * ((p.M + 287) / 288), t8 = tnb * ((p.M + 255) / 256);
-    int mr = 0;
-    if (variant == 6) mr = 9;
-    else if (variant == 7) mr = 8;
-    else if (variant == 1 && g_nt_variant == 0 && p.splitk == 1) {
+  if constexpr (kBigEpi<EPI>) {
+    int cfg = -1, old_mr = 0;
+    if (variant >= 10 && variant <= 12) cfg = variant - 10;
+    else if (variant == 6) old_mr = 9;
+    else if (variant == 7) old_mr = 8;
+    else if (variant == 0) {
+      // Big tiles (one 8-wave workgroup per CU) are taken when their rounds of 256 workgroups are well
+      // filled, counting tile padding: useful outputs / (rounds * 256 * tile area) >= 0.6 - e.g. M = 5760,
+      // N = 3072 -> 20 x 12 = 240 tiles of 288 x 256 (0.94).  N = 800 outputs (5 x 160 columns exactly)
+      // take the 256x160 tile from 100 tiles up: a round of 115 leaves CUs to the weight-gradient stream.
+      const int tnb = (p.N + 255) / 256;
+      const int t9 = tnb * ((p.M + 287) / 288), t8 = tnb * ((p.M + 255) / 256);
       const double useful = (double)p.M * p.N;
       const double e9 = useful / ((double)((t9 + 255) / 256) * 256 * 288 * 256);
       const double e8 = useful / ((double)((t8 + 255) / 256) * 256 * 256 * 256);
-      if (e9 >= 0.6 || e8 >= 0.6) mr = (e8 > e9) ? 8 : 9;
+      const int t160 = ((p.N + 159) / 160) * ((p.M + 255) / 256);
+      if (e9 >= 0.6 || e8 >= 0.6) {
+        if (g_big_impl) cfg = (e8 > e9) ? BIG_256x256 : BIG_288x256;
+        else old_mr = (e8 > e9) ? 8 : 9;
+      } else if (g_big_impl && p.N % 160 == 0 && p.N <= 960 && t160 >= 100) {
+        cfg = BIG_256x160;
+      }
     }
-    if (mr == 9) {
+    if (cfg >= 0 && (EPI != EPI_HEADS || (p.M < 65536 && p.N < 65536))) {
+      int bm = 0, bn = 0;
+      big_tile_dims(cfg, &bm, &bn);
+      const int tm = (p.M + bm - 1) / bm, tnn = (p.N + bn - 1) / bn;
+      p.band = user_band > 0 ? user_band : band_for(tm * tnn, tm, bm, bn);
+      return launch_big_nt(cfg, EPI, p, s);
+    }
+    if (old_mr == 9) {
       constexpr int LDSB = 4 * (288 + 256) * 64;
       static bool once = false;
       if (!once) {
@@ -900,10 +934,11 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         once = true;
       }
-      hipLaunchKernelGGL((gemm_nt_big_kernel<EPI, 9>), dim3(t9), dim3(512), LDSB, s, p);
+      hipLaunchKernelGGL((gemm_nt_big_kernel<EPI, 9>), dim3(((p.N + 255) / 256) * ((p.M + 287) / 288)), dim3(512),
+                         LDSB, s, p);
       return 0;
     }
-    if (mr == 8) {
+    if (old_mr == 8) {
       constexpr int LDSB = 4 * (256 + 256) * 64;
       static bool once = false;
       if (!once) {
@@ -911,7 +946,8 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         once = true;
       }
-      hipLaunchKernelGGL((gemm_nt_big_kernel<EPI, 8>), dim3(t8), dim3(512), LDSB, s, p);
+      hipLaunchKernelGGL((gemm_nt_big_kernel<EPI, 8>), dim3(((p.N + 255) / 256) * ((p.M + 255) / 256)), dim3(512),
+                         LDSB, s, p);
       return 0;
     }
   }
@@ -943,6 +979,7 @@ int check_common(const GemmParams& p, int epi) {
 }  // namespace
 
 void gemm_set_nt_variant(int v) { g_nt_variant = v; }
+void gemm_set_big_impl(int v) { g_big_impl = v; }
 void gemm_set_nt_band(int band) { g_nt_band = band; }
 
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t s) {

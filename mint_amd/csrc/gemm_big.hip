@@ -1,0 +1,720 @@
+// Big-tile bf16 MFMA GEMM family for gfx950: ONE workgroup per CU, 8 waves, 32-deep K stages in a 4-deep
+// LDS ring filled by 16-byte LDS-DMA (global_load_lds_dwordx4) and retired with COUNTED vmcnt waits, the
+// two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) half a K step apart so that the LDS pipe
+// (fragment reads + DMA issue of one group) and the MFMA pipe (the other group) of every SIMD run at the
+// same time.  The structure was developed for the 288x256 NT kernel in round 1 (gemm.hip); here
+// it is generalised over
+//   * the tile shape: wave grid WGM x WGN (2x4 or 4x2), MR x NR MFMA tiles of 16x16 per wave
+//       288x256 (2,9,4,4)   256x256 (2,8,4,4)   N = 3072 / 2400 outputs (FFN1, GELU' dgrad, QKV)
+//       256x160 (4,4,2,5)                       N = 800 outputs: 800 = 5 x 160 exactly, and one wave's 80
+//                                               columns are exactly one attention head (dh = 80)
+//       160x256 (2,5,4,4)                       weight gradients with an 800-row side
+//   * the operand layout:
+//       NT  A[m][k], B[n][k]  (contraction contiguous)  forward / dgrad   - ds_read_b128 fragments
+//       TN  A[k][m], B[k][n]  (contraction = tokens)    wgrad             - ds_read_b64_tr_b16 fragments
+//     so the weight gradients get the same pipeline as the forward GEMMs and need no split-K: a layer's
+//     four wgrad GEMMs are ONE grouped launch of 190 whole-K tiles (fp32 read-modify-write of the grad
+//     arena, no slabs, no reduce pass).
+// MFMA roles are swapped (N-side fragment as the A operand) so that a lane owns 4 consecutive output
+// columns; a problem flagged `trans_out` (dW stored as [n][m]) uses the un-swapped roles instead, which
+// leaves 4 consecutive m per lane = 16 contiguous bytes of the transposed output.
+#include "gemm.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+DEVINL void glds16(const bf16_t* src, unsigned char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)lds_dst, 16, 0, 0);
+}
+template <int N>
+DEVINL void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `stages_after` later stages (LPS loads each) are still in flight
+template <int LPS>
+DEVINL void wait_stages(int stages_after) {
+  switch (stages_after) {
+    case 0: wait_vmcnt<0>(); break;
+    case 1: wait_vmcnt<LPS>(); break;
+    case 2: wait_vmcnt<2 * LPS>(); break;
+    default: wait_vmcnt<3 * LPS>(); break;
+  }
+}
+DEVINL unsigned lds_addr(const unsigned char* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+DEVINL bf16x4 tr_read0(unsigned addr) {
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+  return r;
+}
+
+template <int WGM_, int MR_, int WGN_, int NR_>
+struct BigCfg {
+  static constexpr int WGM = WGM_, MR = MR_, WGN = WGN_, NR = NR_;
+  static constexpr int BM = WGM * MR * 16, BN = WGN * NR * 16;
+  static constexpr int NSTAGE = 4, DIST = NSTAGE - 1;
+  static constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16;  // 1 KiB DMA pieces per 32-deep stage
+  static constexpr int A_BYTES = A_PIECES * 1024;
+  static constexpr int NPIECE = A_PIECES + B_PIECES;
+  static constexpr int STAGE_BYTES = NPIECE * 1024;
+  static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
+  static constexpr int LPS_LO = NPIECE / 8, EXTRA = NPIECE % 8;  // waves < EXTRA issue one more piece
+  static_assert(WGM * WGN == 8, "8 waves");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+// ---- NT stage image: [rows][32 k] = 64-byte rows; logical 16-byte chunk c of row r sits at position
+// c ^ G[(r>>2)&3], G = {0,2,3,1}: every ds_read_b128 service group lands on 16 distinct 16-byte bank slots.
+DEVINL int ring_g(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+DEVINL bf16x8 ring_frag(const unsigned char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(tile + row * 64 + ((chunk ^ ring_g(row)) << 4));
+}
+
+// ---- TN stage image of one operand ([32 k][W columns], W = 128*n128 + 32*tail):
+//   n128 sub-images [32 k][128 cols] with 256-byte rows: logical 32-byte unit u of row k at unit position
+//     u ^ f(k), f(k) = (k&3) | ((k>>3)&1)<<2  (the layout of the 128x128 TN kernel of gemm.hip): the 8 row
+//     segments one ds_read_b64_tr_b16 half-wave touches fall in 8 distinct 32-byte bank slots;
+//   then, if W % 128 == 32, one sub-image [32 k][32 cols] with 64-byte rows: unit u (0/1) of row k at
+//     position u ^ ((k>>3)&1)  (rows k..k+3 cover slots {0,2,4,6} + u, rows k+8.. the other parity).
+// A 16-column MFMA tile is one unit.  Fragment for unit U: lane group g = lane>>4, s = lane&15 supplies the
+// address of 4 contiguous columns (s&3)*4.. of row k = g*8 + hh*4 + (s>>2); the hardware returns to lane c
+// the 4 k-values of column c (tests/test_gpu_ops.py probe) -> two reads (hh = 0, 1) give the 8 k-slots.
+DEVINL int tn_f(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+template <int W>
+struct TnImg {
+  static constexpr int N128 = W / 128, TAIL = (W % 128) / 32;
+  static_assert(W % 128 == 0 || W % 128 == 32, "TN operand width");
+  static constexpr int PIECES = W / 16;
+  // source column (relative to the tile) and k row that lane `lane` of DMA piece `p` must fetch
+  DEVINL static void piece_src(int p, int lane, int& k, int& col) {
+    if (p < N128 * 8) {
+      const int sub = p >> 3, pp = p & 7;
+      k = pp * 4 + (lane >> 4);
+      const int lp = lane & 15;
+      col = sub * 128 + ((((lp >> 1) ^ tn_f(k)) << 1) | (lp & 1)) * 8;
+    } else {
+      const int tp = p - N128 * 8;
+      k = tp * 16 + (lane >> 2);
+      const int cp = lane & 3;
+      col = N128 * 128 + ((((cp >> 1) ^ ((k >> 3) & 1)) << 1) | (cp & 1)) * 8;
+    }
+  }
+  // byte offset (inside the operand image) of the hh = 0 read of unit U, and the hh = 1 increment
+  DEVINL static void frag_off(int U, int lane, unsigned& off0, unsigned& dhh) {
+    const int g = lane >> 4, s = lane & 15;
+    if (U < N128 * 8) {
+      const int sub = U >> 3, u = U & 7;
+      const int f = ((s >> 2) & 3) | ((g & 1) << 2);
+      off0 = (unsigned)(sub * 8192 + (g * 8 + (s >> 2)) * 256 + ((u ^ f) << 5) + (s & 3) * 8);
+      dhh = 4 * 256;
+    } else {
+      const int u = U - N128 * 8;
+      off0 = (unsigned)(N128 * 8192 + (g * 8 + (s >> 2)) * 64 + ((u ^ (g & 1)) << 5) + (s & 3) * 8);
+      dhh = 4 * 64;
+    }
+  }
+};
+
+// -------------------------------------------------------------------------------------------------
+// Shared main loop.  On entry `src[i]` / `dst[i]` / `adv[i]` describe this wave's DMA pieces (source
+// pointer of stage 0, byte offset inside a stage, elements to advance per stage); on exit acc holds the
+// wave's (MR*16) x (NR*16) sub-tile.  SWAP: swapped MFMA roles (lane owns 4 consecutive n of one m).
+// -------------------------------------------------------------------------------------------------
+template <class C, bool TN, bool SWAP>
+DEVINL void big_mainloop(unsigned char* smem, const bf16_t* (&src)[C::LPS_LO + 1], const int (&dst)[C::LPS_LO + 1],
+                         const size_t (&adv)[C::LPS_LO + 1], int nk, int wave, int wm, int wn, int lane,
+                         f32x4 (&acc)[C::MR][C::NR]) {
+  constexpr int MR = C::MR, NR = C::NR, NSTAGE = C::NSTAGE, DIST = C::DIST;
+  constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
+  const int grp = wave >> 2;  // stagger group: waves 0-3 lead, waves 4-7 run one phase behind
+
+  auto stage = [&](int kt) {
+    unsigned char* base = smem + (kt % NSTAGE) * C::STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < LPS_LO; ++i) {
+      glds16(src[i], base + dst[i]);
+      if constexpr (TN) src[i] += adv[i];
+      else src[i] += 32;
+    }
+    if (EXTRA && wave < EXTRA) {
+      glds16(src[LPS_LO], base + dst[LPS_LO]);
+      if constexpr (TN) src[LPS_LO] += adv[LPS_LO];
+      else src[LPS_LO] += 32;
+    }
+  };
+  auto wait_for = [&](int stages_after) {  // wave-uniform: this wave has LPS_LO (+1) loads per stage
+    if (EXTRA && wave < EXTRA) wait_stages<LPS_LO + 1>(stages_after);
+    else wait_stages<LPS_LO>(stages_after);
+  };
+
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // TN fragment addressing (per-lane byte offsets inside a stage, hh = 0; dhh = increment to hh = 1)
+  unsigned aoff[MR], boff[NR], adh[MR], bdh[NR];
+  if constexpr (TN) {
+#pragma unroll
+    for (int i = 0; i < MR; ++i) TnImg<C::BM>::frag_off(wm * MR + i, lane, aoff[i], adh[i]);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      TnImg<C::BN>::frag_off(wn * NR + j, lane, boff[j], bdh[j]);
+      boff[j] += C::A_BYTES;
+    }
+  }
+
+#pragma unroll
+  for (int s2 = 0; s2 < DIST; ++s2)
+    if (s2 < nk) stage(s2);
+  wait_for(min(DIST - 1, nk - 1));
+  __builtin_amdgcn_s_barrier();  // stage 0 landed
+
+  //   phase 2k   : group 0 stages k+3 and reads k      | group 1 multiplies k-1
+  //   phase 2k+1 : group 0 multiplies k                | group 1 stages k+3 and reads k
+  // Every wave retires its own pieces of stage k+1 (counted vmcnt) before the barrier that ends phase 2k+1
+  // and its fragment reads (lgkmcnt) before the barrier that ends its read phase, so a ring slot is only
+  // re-armed after both groups are done with it (see gemm.hip gemm_nt_big_kernel for the derivation).
+  bf16x8 af[MR], bfr[NR];
+  auto read_frags = [&](int kt) {
+    if (kt + DIST < nk) stage(kt + DIST);
+    const unsigned char* As = smem + (kt % NSTAGE) * C::STAGE_BYTES;
+    if constexpr (!TN) {
+      const unsigned char* Bs = As + C::A_BYTES;
+      const int chunk = lane >> 4;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) bfr[j] = ring_frag(Bs, wn * (16 * NR) + j * 16 + (lane & 15), chunk);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) af[i] = ring_frag(As, wm * (16 * MR) + i * 16 + (lane & 15), chunk);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      const unsigned s0 = lds_addr(As);
+      bf16x4 blo[NR], bhi[NR], alo[MR], ahi[MR];
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        blo[j] = tr_read0(s0 + boff[j]);
+        bhi[j] = tr_read0(s0 + boff[j] + bdh[j]);
+      }
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        alo[i] = tr_read0(s0 + aoff[i]);
+        ahi[i] = tr_read0(s0 + aoff[i] + adh[i]);
+      }
+      // the asm reads are invisible to hipcc's counters: retire them by hand and pin the order
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) bfr[j] = __builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) af[i] = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+  };
+  auto multiply = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+        acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one phase behind group 0
+  for (int kt = 0; kt < nk; ++kt) {
+    read_frags(kt);
+    if (grp == 1 && kt + 1 < nk) wait_for(min(DIST - 1, nk - 2 - kt));
+    __builtin_amdgcn_s_barrier();
+    multiply();
+    if (grp == 0 && kt + 1 < nk) wait_for(min(DIST - 1, nk - 2 - kt));
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+// XCD-aware re-deal of the 1-D grid: block b runs on XCD b % 8 (observed); each XCD gets a contiguous
+// range of logical ids so neighbouring tiles (shared operand panels) hit one private L2.  Bijective.
+DEVINL int xcd_logical_id() {
+  const int nwg = gridDim.x, orig = blockIdx.x;
+  const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+}
+
+// exact x / d for x < 65536, d < 65536 with magic = 2^32 / d + 1 (host)
+DEVINL unsigned fastdiv(unsigned x, unsigned magic) { return __umulhi(x, magic); }
+
+// -------------------------------------------------------------------------------------------------
+// NT kernel: C = A B^T with the fused epilogues of gemm.h.  bf16 / fp32 row outputs leave through a
+// wave-private staging area in the (idle) stage ring so that every lane stores 16 bytes of a whole row
+// segment (a wave store in the MFMA layout covers 16 rows x 32 / 64 B; under contention that costs 10-20 %
+// of the launch).  Staging rows carry one 16-byte pad chunk (conflict-free ds_write_b128, 2-way
+// ds_write_b64, linear ds_read_b128).
+// -------------------------------------------------------------------------------------------------
+template <int EPI>
+constexpr bool kStagedBf16 = (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD || EPI == EPI_HEADS);
+template <int EPI>
+constexpr bool kStagedF32 = (EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_RESID);
+
+template <int EPI>
+DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f32x4 v);
+
+template <class C, int EPI>
+__global__ __launch_bounds__(512, 1) void big_nt_kernel(const GemmParams p) {
+  constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
+
+  const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM - 1) / BM;
+  int m0, n0;
+  {
+    const int id = xcd_logical_id();
+    // bands of `band` m-tiles, m fastest inside a band: the ~32 tiles of an XCD form a near-square patch
+    const int band = p.band > 0 ? p.band : 4, per = band * tn;  // host: band_for() (near-square XCD patch)
+    const int b = id / per, w = id - b * per;
+    const int hb = min(band, tm - b * band);
+    m0 = (b * band + w % hb) * BM;
+    n0 = (w / hb) * BN;
+  }
+  const int nk = p.K / 32;
+
+  const bf16_t* src[C::LPS_LO + 1];
+  int dst[C::LPS_LO + 1];
+  size_t adv[C::LPS_LO + 1];
+  {
+    const int lrow = lane >> 2;                     // row inside the 16-row piece
+    const int lchunk = (lane & 3) ^ ring_g(lrow);   // logical 16-byte chunk this lane fetches
+#pragma unroll
+    for (int i = 0; i < C::LPS_LO + 1; ++i) {
+      const int q = (i < C::LPS_LO) ? wave * C::LPS_LO + i : 8 * C::LPS_LO + wave;  // extras: pieces 8*LPS_LO..
+      const int qq = min(q, C::NPIECE - 1);
+      if (qq < C::A_PIECES) {
+        src[i] = p.A + (size_t)min(m0 + qq * 16 + lrow, p.M - 1) * p.lda + lchunk * 8;
+        dst[i] = qq * 1024;
+      } else {
+        src[i] = p.B + (size_t)min(n0 + (qq - C::A_PIECES) * 16 + lrow, p.N - 1) * p.ldb + lchunk * 8;
+        dst[i] = C::A_BYTES + (qq - C::A_PIECES) * 1024;
+      }
+      adv[i] = 32;
+    }
+  }
+  f32x4 acc[MR][NR];
+  big_mainloop<C, false, true>(smem, src, dst, adv, nk, wave, wm, wn, lane, acc);
+
+  const EpiParams& ep = p.ep;
+  const int wrow0 = m0 + wm * (16 * MR), wcol0 = n0 + wn * (16 * NR);
+  if constexpr (kStagedBf16<EPI>) {
+    constexpr int NOUT = (EPI == EPI_BIAS_GELU) ? 2 : 1;
+    constexpr int ROWB = NR * 32, STR = ROWB + 16, CPR = ROWB / 16;  // bf16 staging row, chunks per row
+    // rows per pass: largest divisor CH of MR whose 8 wave regions fit the ring
+    constexpr int CH = (8 * NOUT * MR * 16 * STR <= C::LDS_BYTES)                             ? MR
+                       : (MR % 2 == 0 && 8 * NOUT * (MR / 2) * 16 * STR <= C::LDS_BYTES)     ? MR / 2
+                       : (MR % 3 == 0 && 8 * NOUT * (MR / 3) * 16 * STR <= C::LDS_BYTES)     ? MR / 3
+                       : (MR % 4 == 0 && 8 * NOUT * (MR / 4) * 16 * STR <= C::LDS_BYTES)     ? MR / 4
+                                                                                              : 1;
+    constexpr int REG = CH * 16 * STR;
+    constexpr int TOT = CH * 16 * CPR, IT = (TOT + 63) / 64;  // 16-byte chunks of one pass, per-lane trips
+    bool aligned = !(p.N & 7) && (NOUT == 1 || !(ep.ldo1 & 7)) && (EPI != EPI_GELU_BWD || !(ep.ldp & 7));
+    if constexpr (EPI == EPI_HEADS) aligned = aligned && !(ep.dh & 7) && !(ep.dhp & 7);
+    else aligned = aligned && !(ep.ldo0 & 7);
+    if (aligned) {
+      unsigned char* stg = smem + wave * (NOUT * REG);
+      bf16_t* h0 = ep.hrow[0];
+      bf16_t* h1 = ep.hrow[1];
+      bf16_t* h2 = ep.hrow[2];
+#pragma unroll
+      for (int c = 0; c < MR / CH; ++c) {
+        const int prow0 = wrow0 + c * CH * 16;
+        if constexpr (EPI == EPI_GELU_BWD) {
+          // the saved pre-activation comes in the way the result goes out: whole row segments into the
+          // staging image, then each lane picks its 4 values at the offset it will overwrite
+          bf16x8 pv[IT];
+#pragma unroll
+          for (int it = 0; it < IT; ++it) {
+            const int q = it * 64 + lane;
+            const int lr = q / CPR, ch = q - lr * CPR;
+            const int row = min(prow0 + lr, p.M - 1), col = wcol0 + ch * 8;
+            pv[it] = bf16x8{};
+            if (q < TOT && col < p.N) pv[it] = *reinterpret_cast<const bf16x8*>(ep.pre + (size_t)row * ep.ldp + col);
+          }
+#pragma unroll
+          for (int it = 0; it < IT; ++it) {
+            const int q = it * 64 + lane;
+            const int lr = q / CPR, ch = q - lr * CPR;
+            if (q < TOT) *reinterpret_cast<bf16x8*>(stg + lr * STR + ch * 16) = pv[it];
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii) {
+          const int i = c * CH + ii;
+          const int lr = ii * 16 + (lane & 15);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            const int lc = j * 16 + (lane >> 4) * 4;
+            const int col = wcol0 + lc;
+            const f32x4 v = acc[i][j];
+            const int off = lr * STR + lc * 2;
+            bf16x4 o0, o1;
+            if constexpr (EPI == EPI_BF16 || EPI == EPI_HEADS) {
+              o0 = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            } else if constexpr (EPI == EPI_BIAS_GELU) {
+              float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+              if (col < p.N) b = *reinterpret_cast<const float4*>(ep.bias + col);
+              const float x0 = v[0] + b.x, x1 = v[1] + b.y, x2 = v[2] + b.z, x3 = v[3] + b.w;
+              o0 = bf16x4{(bf16_t)x0, (bf16_t)x1, (bf16_t)x2, (bf16_t)x3};
+              o1 = bf16x4{(bf16_t)gelu_tanh(x0), (bf16_t)gelu_tanh(x1), (bf16_t)gelu_tanh(x2), (bf16_t)gelu_tanh(x3)};
+            } else {  // EPI_GELU_BWD
+              const bf16x4 pv = *reinterpret_cast<const bf16x4*>(stg + off);
+              o0 = bf16x4{(bf16_t)(v[0] * gelu_tanh_grad((float)pv[0])), (bf16_t)(v[1] * gelu_tanh_grad((float)pv[1])),
+                          (bf16_t)(v[2] * gelu_tanh_grad((float)pv[2])), (bf16_t)(v[3] * gelu_tanh_grad((float)pv[3]))};
+            }
+            *reinterpret_cast<bf16x4*>(stg + off) = o0;
+            if constexpr (NOUT == 2) *reinterpret_cast<bf16x4*>(stg + REG + off) = o1;
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int q = it * 64 + lane;
+          const int lr = q / CPR, ch = q - lr * CPR;
+          const int row = prow0 + lr, col = wcol0 + ch * 8;
+          if (q < TOT && row < p.M && col < p.N) {
+            const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + lr * STR + ch * 16);
+            if constexpr (EPI == EPI_HEADS) {
+              // column -> (which, h, d), row -> (b, t); an 8-column chunk never straddles a head (dh % 8 == 0)
+              const unsigned which = fastdiv(col, ep.mg_hid), rem = col - which * ep.hid;
+              const unsigned h = fastdiv(rem, ep.mg_dh), d = rem - h * ep.dh;
+              const unsigned b = fastdiv(row, ep.mg_ntok), t = row - b * ep.n_tok;
+              bf16_t* hr = (which == 0) ? h0 : (which == 1) ? h1 : h2;
+              if (hr) *reinterpret_cast<bf16x8*>(hr + ((size_t)(b * ep.heads + h) * ep.n_pad + t) * ep.dhp + d) = v0;
+            } else {
+              *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v0;
+              if constexpr (NOUT == 2) {
+                const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + REG + lr * STR + ch * 16);
+                *reinterpret_cast<bf16x8*>((bf16_t*)ep.out1 + (size_t)row * ep.ldo1 + col) = v1;
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
+  }
+  if constexpr (kStagedF32<EPI>) {
+    constexpr int ROWB = NR * 64, STR = ROWB + 16, CPR = ROWB / 16;
+    constexpr int CH = (8 * MR * 16 * STR <= C::LDS_BYTES)                          ? MR
+                       : (MR % 2 == 0 && 8 * (MR / 2) * 16 * STR <= C::LDS_BYTES)  ? MR / 2
+                       : (MR % 3 == 0 && 8 * (MR / 3) * 16 * STR <= C::LDS_BYTES)  ? MR / 3
+                       : (MR % 4 == 0 && 8 * (MR / 4) * 16 * STR <= C::LDS_BYTES)  ? MR / 4
+                                                                                   : 1;
+    constexpr int REG = CH * 16 * STR;
+    constexpr int TOT = CH * 16 * CPR, IT = (TOT + 63) / 64;
+    const bool aligned = !(p.N & 3) && !(ep.ldo0 & 3) && (EPI != EPI_F32_BIAS_RESID || !(ep.ldr & 3));
+    if (aligned) {
+      unsigned char* stg = smem + wave * REG;
+#pragma unroll
+      for (int c = 0; c < MR / CH; ++c) {
+        const int prow0 = wrow0 + c * CH * 16;
+        // the fp32 residual rows of this pass are requested first, whole row segments per wave load; their
+        // latency hides behind the accumulator -> LDS re-shape below
+        float4 rv[IT];
+        if constexpr (EPI == EPI_F32_BIAS_RESID) {
+#pragma unroll
+          for (int it = 0; it < IT; ++it) {
+            const int q = it * 64 + lane;
+            const int lr = q / CPR, ch = q - lr * CPR;
+            const int row = prow0 + lr, col = wcol0 + ch * 4;
+            rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q < TOT && row < p.M && col < p.N)
+              rv[it] = *reinterpret_cast<const float4*>(ep.resid + (size_t)row * ep.ldr + col);
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < CH; ++ii) {
+          const int lr = ii * 16 + (lane & 15);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) {
+            const f32x4 v = acc[c * CH + ii][j];
+            *reinterpret_cast<float4*>(stg + lr * STR + (j * 16 + (lane >> 4) * 4) * 4) =
+                make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+          const int q = it * 64 + lane;
+          const int lr = q / CPR, ch = q - lr * CPR;
+          const int row = prow0 + lr, col = wcol0 + ch * 4;
+          if (q < TOT && row < p.M && col < p.N) {
+            float4 v = *reinterpret_cast<const float4*>(stg + lr * STR + ch * 16);
+            if (ep.bias) {
+              const float4 b = *reinterpret_cast<const float4*>(ep.bias + col);
+              v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+            }
+            if constexpr (EPI == EPI_F32_BIAS_RESID) {
+              v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w;
+            }
+            *reinterpret_cast<float4*>((float*)ep.out0 + (size_t)row * ep.ldo0 + col) = v;
+          }
+        }
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+      direct_store<EPI>(ep, p.M, p.N, wrow0 + i * 16 + (lane & 15), wcol0 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+}
+
+// One lane's share of the un-staged epilogue: output row `row`, columns col0..col0+3 (col0 % 4 == 0).
+template <int EPI>
+DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f32x4 v) {
+  if (row >= M || col0 >= N) return;
+  if constexpr (EPI == EPI_BF16) {
+    bf16_t* o = (bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col0 + r < N) o[r] = (bf16_t)v[r];
+  } else if constexpr (EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_POS || EPI == EPI_F32_BIAS_RESID) {
+    float* o = (float*)ep.out0 + (size_t)row * ep.ldo0 + col0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col0 + r < N) {
+        float x = v[r] + (ep.bias ? ep.bias[col0 + r] : 0.f);
+        if constexpr (EPI == EPI_F32_BIAS_POS) x += ep.pos[(size_t)(row % ep.seq) * N + col0 + r];
+        if constexpr (EPI == EPI_F32_BIAS_RESID) x += ep.resid[(size_t)row * ep.ldr + col0 + r];
+        o[r] = x;
+      }
+  } else if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col0 + r < N) {
+        const float pre = v[r] + ep.bias[col0 + r];
+        ((bf16_t*)ep.out0)[(size_t)row * ep.ldo0 + col0 + r] = (bf16_t)pre;
+        ((bf16_t*)ep.out1)[(size_t)row * ep.ldo1 + col0 + r] = (bf16_t)gelu_tanh(pre);
+      }
+  } else if constexpr (EPI == EPI_GELU_BWD) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col0 + r < N)
+        ((bf16_t*)ep.out0)[(size_t)row * ep.ldo0 + col0 + r] =
+            (bf16_t)(v[r] * gelu_tanh_grad((float)ep.pre[(size_t)row * ep.ldp + col0 + r]));
+  } else if constexpr (EPI == EPI_HEADS) {
+    const int which = col0 / ep.hid, rem = col0 - which * ep.hid;
+    const int h = rem / ep.dh, d = rem - h * ep.dh;
+    const int b = row / ep.n_tok, t = row - b * ep.n_tok;
+    bf16_t* hr = (which == 0) ? ep.hrow[0] : (which == 1) ? ep.hrow[1] : ep.hrow[2];
+    if (hr) {
+      bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      *reinterpret_cast<bf16x4*>(hr + ((size_t)(b * ep.heads + h) * ep.n_pad + t) * ep.dhp + d) = pk;
+    }
+  } else if constexpr (EPI == EPI_F32_BF16) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col0 + r < N) {
+        ((float*)ep.out0)[(size_t)row * ep.ldo0 + col0 + r] = v[r];
+        ((bf16_t*)ep.out1)[(size_t)row * ep.ldo1 + col0 + r] = (bf16_t)v[r];
+      }
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// Grouped TN kernel (weight gradients): out[m][n] += sum_k A[k][m] B[k][n] over the WHOLE K range, fp32.
+// Logical block id -> (problem, m-tile, n-tile), m fastest: with 5 m-tiles per 800-row side the ~24 tiles
+// an XCD owns form a near-square patch (5 x 5 operand panels per K step instead of 24 + 24).
+// -------------------------------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
+  constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / C::WGN, wn = wave % C::WGN;
+
+  const int id = xcd_logical_id();
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < TN_GROUP_MAX; ++i)
+    if (i < g.n && id >= g.p[i].tile_begin) pi = i;
+  // scalar copies (no dynamic indexing of the by-value kernarg struct: that would spill it to scratch)
+  TnProblem pr = g.p[0];
+#pragma unroll
+  for (int i = 1; i < TN_GROUP_MAX; ++i)
+    if (pi == i) pr = g.p[i];
+  const int local = id - pr.tile_begin;
+  const int tmi = local % pr.tiles_m, tni = local / pr.tiles_m;
+  const int m0 = tmi * BM, n0 = tni * BN;
+  const int nk = g.K / 32;
+
+  const bf16_t* src[C::LPS_LO + 1];
+  int dst[C::LPS_LO + 1];
+  size_t adv[C::LPS_LO + 1];
+#pragma unroll
+  for (int i = 0; i < C::LPS_LO + 1; ++i) {
+    const int q = (i < C::LPS_LO) ? wave * C::LPS_LO + i : 8 * C::LPS_LO + wave;
+    const int qq = min(q, C::NPIECE - 1);
+    int k, col;
+    if (qq < C::A_PIECES) {
+      TnImg<BM>::piece_src(qq, lane, k, col);
+      src[i] = pr.A + (size_t)k * pr.lda + min(m0 + col, pr.lda - 8);
+      dst[i] = qq * 1024;
+      adv[i] = (size_t)32 * pr.lda;
+    } else {
+      TnImg<BN>::piece_src(qq - C::A_PIECES, lane, k, col);
+      src[i] = pr.B + (size_t)k * pr.ldb + min(n0 + col, pr.ldb - 8);
+      dst[i] = C::A_BYTES + (qq - C::A_PIECES) * 1024;
+      adv[i] = (size_t)32 * pr.ldb;
+    }
+  }
+  f32x4 acc[MR][NR];
+  const int wrow0 = m0 + wm * (16 * MR), wcol0 = n0 + wn * (16 * NR);
+  if (!pr.trans_out) {
+    big_mainloop<C, true, true>(smem, src, dst, adv, nk, wave, wm, wn, lane, acc);
+    // lane: row m = .. + (lane&15), 4 consecutive n.  All old values are requested before the first store.
+    float4 old[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const int m = wrow0 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int n = wcol0 + j * 16 + (lane >> 4) * 4;
+        old[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < pr.M && n + 3 < pr.N) old[i][j] = *reinterpret_cast<const float4*>(pr.out + (size_t)m * pr.ldo + n);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const int m = wrow0 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int n = wcol0 + j * 16 + (lane >> 4) * 4;
+        if (m < pr.M && n + 3 < pr.N)
+          *reinterpret_cast<float4*>(pr.out + (size_t)m * pr.ldo + n) =
+              make_float4(old[i][j].x + acc[i][j][0], old[i][j].y + acc[i][j][1], old[i][j].z + acc[i][j][2],
+                          old[i][j].w + acc[i][j][3]);
+      }
+    }
+  } else {
+    big_mainloop<C, true, false>(smem, src, dst, adv, nk, wave, wm, wn, lane, acc);
+    // un-swapped roles: lane holds 4 consecutive m of column n = .. + (lane&15); out is [n][m]
+    float4 old[MR][NR];
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const int m = wrow0 + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int n = wcol0 + j * 16 + (lane & 15);
+        old[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < pr.N && m + 3 < pr.M) old[i][j] = *reinterpret_cast<const float4*>(pr.out + (size_t)n * pr.ldo + m);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      const int m = wrow0 + i * 16 + (lane >> 4) * 4;
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int n = wcol0 + j * 16 + (lane & 15);
+        if (n < pr.N && m + 3 < pr.M)
+          *reinterpret_cast<float4*>(pr.out + (size_t)n * pr.ldo + m) =
+              make_float4(old[i][j].x + acc[i][j][0], old[i][j].y + acc[i][j][1], old[i][j].z + acc[i][j][2],
+                          old[i][j].w + acc[i][j][3]);
+      }
+    }
+  }
+}
+
+template <typename K>
+int allow_lds(K kernel, int bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             bytes) == hipSuccess
+             ? 0
+             : -20;
+}
+
+template <class C, int EPI>
+int launch_big_nt_cfg(const GemmParams& p, hipStream_t s) {
+  static bool once = false;
+  if (!once) {
+    if (int rc = allow_lds(big_nt_kernel<C, EPI>, C::LDS_BYTES)) return rc;
+    once = true;
+  }
+  const int tiles = ((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN);
+  hipLaunchKernelGGL((big_nt_kernel<C, EPI>), dim3(tiles), dim3(512), C::LDS_BYTES, s, p);
+  return 0;
+}
+
+using Cfg288x256 = BigCfg<2, 9, 4, 4>;
+using Cfg256x256 = BigCfg<2, 8, 4, 4>;
+using Cfg256x160 = BigCfg<4, 4, 2, 5>;
+using Cfg160x256 = BigCfg<2, 5, 4, 4>;
+
+template <int EPI>
+int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
+  switch (cfg) {
+    case BIG_288x256: return launch_big_nt_cfg<Cfg288x256, EPI>(p, s);
+    case BIG_256x256: return launch_big_nt_cfg<Cfg256x256, EPI>(p, s);
+    case BIG_256x160: return launch_big_nt_cfg<Cfg256x160, EPI>(p, s);
+  }
+  return -7;
+}
+
+unsigned magic_of(int d) { return d > 0 ? (unsigned)((1ull << 32) / (unsigned)d + 1) : 0u; }
+
+}  // namespace
+
+int big_tile_dims(int cfg, int* bm, int* bn) {
+  switch (cfg) {
+    case BIG_288x256: *bm = 288; *bn = 256; return 0;
+    case BIG_256x256: *bm = 256; *bn = 256; return 0;
+    case BIG_256x160: *bm = 256; *bn = 160; return 0;
+    case BIG_160x256: *bm = 160; *bn = 256; return 0;
+  }
+  return -1;
+}
+
+int launch_big_nt(int cfg, int epi, const GemmParams& p_in, hipStream_t s) {
+  GemmParams p = p_in;
+  if (p.K % 32 || p.K < 32 || p.splitk != 1) return -6;
+  if (epi == EPI_HEADS) {
+    if (p.M >= 65536 || p.N >= 65536) return -8;
+    p.ep.mg_hid = magic_of(p.ep.hid);
+    p.ep.mg_dh = magic_of(p.ep.dh);
+    p.ep.mg_ntok = magic_of(p.ep.n_tok);
+  }
+  switch (epi) {
+    case EPI_BF16: return launch_big_nt_epi<EPI_BF16>(cfg, p, s);
+    case EPI_F32_BIAS: return launch_big_nt_epi<EPI_F32_BIAS>(cfg, p, s);
+    case EPI_F32_BIAS_RESID: return launch_big_nt_epi<EPI_F32_BIAS_RESID>(cfg, p, s);
+    case EPI_BIAS_GELU: return launch_big_nt_epi<EPI_BIAS_GELU>(cfg, p, s);
+    case EPI_GELU_BWD: return launch_big_nt_epi<EPI_GELU_BWD>(cfg, p, s);
+    case EPI_HEADS: return launch_big_nt_epi<EPI_HEADS>(cfg, p, s);
+    case EPI_F32_BF16: return launch_big_nt_epi<EPI_F32_BF16>(cfg, p, s);
+  }
+  return -7;
+}
+
+// Whole-K grouped wgrad launch.  Every problem: K % 32 == 0, lda / ldb % 8 == 0 and >= 8, out 16-byte
+// aligned with ldo % 4 == 0, M % 4 == 0 and N % 4 == 0.  Fills tiles_m / tile_begin.
+int launch_big_tn_group(TnGroup g, hipStream_t s) {
+  using C = Cfg160x256;
+  if (g.n < 1 || g.n > TN_GROUP_MAX || g.K % 32 || g.K < 32) return -1;
+  int total = 0;
+  for (int i = 0; i < g.n; ++i) {
+    TnProblem& q = g.p[i];
+    if ((q.lda & 7) || (q.ldb & 7) || q.lda < 8 || q.ldb < 8 || (q.ldo & 3) || (q.M & 3) || (q.N & 3)) return -2;
+    if (((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15) || ((uintptr_t)q.out & 15)) return -5;
+    q.tiles_m = (q.M + C::BM - 1) / C::BM;
+    q.tile_begin = total;
+    total += q.tiles_m * ((q.N + C::BN - 1) / C::BN);
+  }
+  static bool once = false;
+  if (!once) {
+    if (int rc = allow_lds(big_tn_kernel<C>, C::LDS_BYTES)) return rc;
+    once = true;
+  }
+  hipLaunchKernelGGL((big_tn_kernel<C>), dim3(total), dim3(512), C::LDS_BYTES, s, g);
+  return 0;
+}

@@ -140,6 +140,9 @@ class FACTModel:
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self._device)
         if self._grad_cb_args is not None:  # handle was re-created: re-register the bucket callback
             self.set_grad_callback(*self._grad_cb_args)
+        if getattr(self, "_pending_state", None) is not None:
+            state, self._pending_state = self._pending_state, None
+            self.load_state_dict(state)
 
     def _init_parameters(self):
         """Reference initialisers: glorot_uniform Dense kernels and zero biases
@@ -167,18 +170,25 @@ class FACTModel:
             x = torch.as_tensor(x)
         return x.to(device=self._device, dtype=torch.float32).contiguous()
 
-    def _inputs(self, inputs):
+    def _inputs(self, inputs, ar=False):
+        """Validate and stage the two modal inputs.  Shapes are checked BEFORE raw pointers reach the
+        C ABI (the engine indexes with the configured strides): the reference fails at the position
+        embedding add (base_models.py:148-156) for any other sequence length / feature width.
+        `ar=True` (auto-regressive sampling) admits an audio track longer than the window."""
         motion = self._prep(inputs["motion_input"])
         audio = self._prep(inputs["audio_input"])
         if motion.dim() != 3 or audio.dim() != 3 or motion.shape[0] != audio.shape[0]:
             raise ValueError("motion_input/audio_input must be [batch, seq, feature] with equal batch")
         self.build(motion.shape[0], motion.shape[2], audio.shape[2])
         p = self.feature_to_params
-        # the learned position tables are [sequence_length, hidden] (base_models.py:148-156):
-        # any other input length fails the broadcast add in the reference
         if motion.shape[1] != p["motion"]["sequence_length"] or motion.shape[2] != self._feat["motion"]:
             raise ValueError("motion_input shape %s incompatible with [*, %d, %d]" % (
                 tuple(motion.shape), p["motion"]["sequence_length"], self._feat["motion"]))
+        n_a = p["audio"]["sequence_length"]
+        bad_len = (audio.shape[1] < n_a) if ar else (audio.shape[1] != n_a)
+        if bad_len or audio.shape[2] != self._feat["audio"]:
+            raise ValueError("audio_input shape %s incompatible with [*, %s%d, %d]" % (
+                tuple(audio.shape), ">=" if ar else "", n_a, self._feat["audio"]))
         return motion, audio
 
     def __call__(self, inputs, training=True):
@@ -189,9 +199,6 @@ class FACTModel:
         Returns [batch, motion_seq + audio_seq, out_dim]; only the first N frames are supervised."""
         motion, audio = self._inputs(inputs)
         p = self.feature_to_params
-        if audio.shape[1] != p["audio"]["sequence_length"] or audio.shape[2] != self._feat["audio"]:
-            raise ValueError("audio_input shape %s incompatible with [*, %d, %d]" % (
-                tuple(audio.shape), p["audio"]["sequence_length"], self._feat["audio"]))
         B = motion.shape[0]
         n = p["motion"]["sequence_length"] + p["audio"]["sequence_length"]
         out = torch.empty(B, n, self._out_dim, dtype=torch.float32, device=self._device)
@@ -202,9 +209,10 @@ class FACTModel:
         """Auto-regressive generation (fact_model.py:103-132): keep frame 0 of each forward, shift
         the motion window by one, slide the audio window by one; stops early when the audio runs
         out. Returns [batch, steps_done, out_dim]."""
-        motion = self._prep(inputs["motion_input"])
-        audio = self._prep(inputs["audio_input"])
-        self.build(motion.shape[0], motion.shape[2], audio.shape[2])
+        motion, audio = self._inputs(inputs, ar=True)
+        if self._out_dim != self._feat["motion"]:
+            raise ValueError("auto-regressive inference feeds outputs back as motion frames: out_dim %d != "
+                             "motion feature_dim %d" % (self._out_dim, self._feat["motion"]))
         B, audio_len = motion.shape[0], audio.shape[1]
         out = torch.empty(B, max(steps, 1), self._out_dim, dtype=torch.float32, device=self._device)
         done = C.c_int(0)
@@ -241,6 +249,11 @@ class FACTModel:
             raise RuntimeError("model was built with is_training=False")
         motion, audio = self._inputs(inputs)
         target = self._prep(target)
+        n_tot = self.feature_to_params["motion"]["sequence_length"] + self.feature_to_params["audio"]["sequence_length"]
+        if (target.dim() != 3 or target.shape[0] != motion.shape[0] or target.shape[2] != self._out_dim
+                or not (0 < target.shape[1] <= n_tot)):
+            raise ValueError("target shape %s incompatible with [%d, 1..%d, %d]" % (
+                tuple(target.shape), motion.shape[0], n_tot, self._out_dim))
         B, T = target.shape[0], target.shape[1]
         L.check(L.lib().fact_forward_backward(self._h, L.ptr(motion), L.ptr(audio), L.ptr(target), B, T,
                                               float(loss_scale), L.ptr(self._loss_buf), L.cur_stream()))
@@ -256,6 +269,11 @@ class FACTModel:
         self._require_built()
         L.check(L.lib().fact_adam_begin(self._h, float(lr), float(beta_1), float(beta_2), float(epsilon)))
         self.global_step += 1
+
+    def cancel_fused_adam(self, global_step):
+        """Disarm a begin_fused_adam whose forward_backward never ran (it raised before reaching the engine)."""
+        L.check(L.lib().fact_adam_cancel(self._h))
+        self.global_step = int(global_step)
 
     def adam_bucket(self, bucket, stream):
         L.check(L.lib().fact_adam_bucket(self._h, int(bucket), C.c_void_p(stream.cuda_stream)))
@@ -326,7 +344,10 @@ class FACTModel:
         return d
 
     def load_state_dict(self, state):
-        self._require_built()
+        if self._h is None:  # deferred restore: applied by build() right after the variables exist
+            self._pending_state = state
+            self.global_step = int(state.get("global_step", 0))
+            return
         for k in self._arena:
             if k in state:
                 self._arena[k].copy_(state[k])

@@ -29,6 +29,9 @@ def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_traini
     drop the remainder; eval: one pass in file order, remainder kept."""
     batch_size = train_eval_config.batch_size
     files = sorted(_glob.glob(dataset_config.data_files))
+    if not files:
+        # tf.data.Dataset.list_files raises on an empty match; a training generator would otherwise spin forever
+        raise ValueError("data_files pattern %r matched no files" % dataset_config.data_files)
     params = inputs_util.get_modality_to_param_dict(dataset_config)
     use_fact = any(o.WhichOneof("preprocessor") == "fact_preprocessor"
                    for o in dataset_config.data_augmentation_options)

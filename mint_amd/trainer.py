@@ -81,6 +81,14 @@ def allreduce_gradients(grad_arena, bucket_bytes=64 << 20, async_op=False):
     return works
 
 
+def clip_local_gradients(grad_arena, clip_norm):
+    """tf.clip_by_global_norm on this replica's flat gradient arena (alignment padding is zero), in place,
+    no host sync.  Only used when clipping is requested under data parallelism (not the shipped config)."""
+    norm = torch.linalg.vector_norm(grad_arena)
+    grad_arena.mul_(clip_norm / torch.clamp(norm, min=clip_norm))
+    return norm
+
+
 class OverlappedGradReducer:
     """Sum-all-reduces gradient buckets on a dedicated communication stream WHILE the backward pass
     is still running: the engine reports each contiguous bucket as soon as its producers are
@@ -145,7 +153,8 @@ class SingleTaskTrainer:
         if overlap_grad_allreduce is None:
             overlap_grad_allreduce = (self.num_replicas_in_sync > 1 and hasattr(model, "set_grad_callback")
                                       and dist.get_backend() == "nccl")
-        self._overlap = bool(overlap_grad_allreduce)  # reducer is created lazily (model builds on 1st batch)
+        # per-replica clipping needs the whole local gradient before anything is summed: no bucket overlap then
+        self._overlap = bool(overlap_grad_allreduce) and not (grad_clip_norm > 0.)  # reducer is created lazily
         # Optimizer step inside backward (engine API, no global-norm clipping), single replica only: the
         # engine holds the head + cross-modal buckets back until the cross-modal backward is done and
         # updates them beside the two small encoder stacks' backward (10.27 vs 10.35 ms/step at B = 16).
@@ -177,28 +186,47 @@ class SingleTaskTrainer:
             self._reducer = OverlappedGradReducer(self.model)
         # fused path: single replica without a gradient callback (the engine updates the buckets itself)
         fused = self._fuse and R == 1 and self._reducer is None
-        lr = None
+        step = self.optimizer.iterations  # summaries are written at the PRE-update step (:172-173)
+        lr_used = None
         if fused:
-            lr = self.optimizer.begin_fused(self.model)
+            snap = (self.optimizer.iterations, self.model.global_step)
+            lr_used = self.optimizer.begin_fused(self.model)
         elif self._reducer is not None:
             self._reducer.fused_adam = False
-        raw_loss = self.model.forward_backward(inputs, target, loss_scale=1.0 / R)
+        try:
+            raw_loss = self.model.forward_backward(inputs, target, loss_scale=1.0 / R)
+        except Exception:
+            if fused:  # disarm the in-backward optimizer and roll the counters back
+                self.optimizer.iterations, self.model.global_step = snap
+                if hasattr(self.model, "cancel_fused_adam"):
+                    self.model.cancel_fused_adam(snap[1])
+            raise
         loss = raw_loss / R
         regularization_loss = 0.0  # model.losses is empty: no regularisers
         total_loss = loss + regularization_loss
         if self.summary_fn:
-            self.summary_fn({"total_loss": total_loss, "loss:": loss, "reg_loss": regularization_loss},
-                            self.optimizer.iterations)
+            self.summary_fn({"total_loss": total_loss, "loss:": loss, "reg_loss": regularization_loss}, step)
+        clip_in_adam = self.grad_clip_norm
+        if R > 1 and self.grad_clip_norm > 0.:
+            # tf.clip_by_global_norm runs on each replica's OWN gradient before apply_gradients sums
+            # them (:180-187): scale the local arena first, then reduce; nothing is left for Adam to clip
+            clip_local_gradients(self.model.grad_arena, self.grad_clip_norm)
+            clip_in_adam = 0.0
         if self._reducer is not None:
             self._reducer.finish()
         elif not fused:
             allreduce_gradients(self.model.grad_arena)
         if not fused:
-            lr = self.optimizer.apply_gradients(self.model, clip_norm=self.grad_clip_norm)
+            lr_used = self.optimizer.apply_gradients(self.model, clip_norm=clip_in_adam)
         self.train_loss.update_state(total_loss)
         self.task_loss.update_state(loss)
         self.regularization_loss.update_state(regularization_loss)
-        self.learning_rate.update_state(lr)
+        # the reference reports the schedule at the POST-increment iteration count (:192-193)
+        self.learning_rate.update_state(self.optimizer.learning_rate(self.optimizer.iterations))
+        if self.metrics:  # user metrics see (target, output): costs one extra forward pass
+            output = self.model(inputs, training=True)
+            for metric in self.metrics:
+                metric.update_state(target, output)
         return total_loss
 
     def train_loop_end(self):

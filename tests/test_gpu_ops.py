@@ -104,10 +104,11 @@ def gemm_path(request):
     L.lib().fact_debug_force_generic_gemm(0)
 
 
-@pytest.fixture(params=[0, 1, 6, 7], ids=["auto", "tile128", "big288", "big256"])
+@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12],
+                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160"])
 def nt_variant(request):
-    """NT kernel choice: the engine's automatic pick, the 128x128 kernel, and both big-tile kernels
-    (288x256 / 256x256, staggered wave groups) forced regardless of the tile-count heuristic."""
+    """NT kernel choice: the engine's automatic pick, the 128x128 kernel, the round-1 big-tile kernels and
+    every tile config of the big-tile family (gemm_big.hip), forced regardless of the tile-count heuristic."""
     L.lib().fact_debug_gemm_nt_variant(request.param)
     yield request.param
     L.lib().fact_debug_gemm_nt_variant(0)
@@ -208,6 +209,57 @@ def test_gemm_tn(gemm_path, use_tr, K, Mo, No, splitk):
     assert _rel_err(out, ref) < 1e-4
 
 
+def _tn_group(probs, K):
+    """probs: list of (A [K][lda] bf16, Mo, B [K][ldb] bf16, No, out fp32, trans)."""
+    lib = L.lib()
+    n = len(probs)
+    VP, IA = C.c_void_p * n, C.c_int * n
+    A = VP(*[p[0].data_ptr() for p in probs]); lda = IA(*[p[0].stride(0) for p in probs])
+    B = VP(*[p[2].data_ptr() for p in probs]); ldb = IA(*[p[2].stride(0) for p in probs])
+    out = VP(*[p[4].data_ptr() for p in probs]); ldo = IA(*[p[4].stride(0) for p in probs])
+    Mo = IA(*[p[1] for p in probs]); No = IA(*[p[3] for p in probs]); tr = IA(*[p[5] for p in probs])
+    L.check(lib.fact_op_gemm_tn_group(n, A, lda, B, ldb, out, ldo, Mo, No, tr, K, L.cur_stream()))
+    _sync()
+
+
+@pytest.mark.parametrize("K", [32, 96, 1440, 5760])
+def test_gemm_tn_group(K):
+    """Grouped whole-K wgrad kernel: the four weight-gradient shapes of a FACT layer in one launch (dW2 stored
+    transposed), ragged column counts (2400 = 9.4 tiles of 256, 800 = 3.1), accumulation into existing values."""
+    g = torch.Generator(device=DEV).manual_seed(31)
+    d, ff, qp, dp, fp = 800, 3072, 2432, 832, 3072
+    def mk(cols, ld):
+        t = torch.zeros(K, ld, device=DEV, dtype=torch.bfloat16)
+        t[:, :cols] = _bf(torch.randn(K, cols, device=DEV, generator=g))
+        return t
+    xin, gact, h2, dpre, att, xmid, h1, dqkv = (mk(d, dp), mk(ff, fp), mk(d, dp), mk(ff, fp), mk(d, dp),
+                                                mk(d, dp), mk(d, dp), mk(3 * d, qp))
+    o2 = torch.full((ff, d), 0.5, device=DEV)
+    o1 = torch.full((d, ff), -1.0, device=DEV)
+    oo = torch.zeros(d, d, device=DEV)
+    oq = torch.full((d, 3 * d), 2.0, device=DEV)
+    _tn_group([(xin, d, gact, ff, o2, 1), (h2, d, dpre, ff, o1, 0), (att, d, xmid, d, oo, 0),
+               (h1, d, dqkv, 3 * d, oq, 0)], K)
+    tol = 2e-3 * math.sqrt(K)
+    _close(o2, 0.5 + gact.float().t() @ xin[:, :d].float(), 1e-3, tol, "dW2 (transposed store)")
+    _close(o1, -1.0 + h2[:, :d].float().t() @ dpre.float(), 1e-3, tol, "dW1")
+    _close(oo, att[:, :d].float().t() @ xmid[:, :d].float(), 1e-3, tol, "dWo")
+    _close(oq, 2.0 + h1[:, :d].float().t() @ dqkv[:, :3 * d].float(), 1e-3, tol, "dWqkv")
+
+
+def test_gemm_tn_group_small_dims():
+    """Other hidden sizes: d = 128 (one partial 160-row tile), d = 1536 (9.6 tiles), single problem."""
+    g = torch.Generator(device=DEV).manual_seed(32)
+    for (K, Mo, No) in [(64, 128, 512), (256, 1536, 384), (128, 160, 256), (96, 164, 260)]:
+        A = _bf(torch.randn(K, (Mo + 63) // 64 * 64, device=DEV, generator=g))
+        B = _bf(torch.randn(K, (No + 63) // 64 * 64, device=DEV, generator=g))
+        for tr in (0, 1):
+            out = torch.ones((No, Mo) if tr else (Mo, No), device=DEV)
+            _tn_group([(A, Mo, B, No, out, tr)], K)
+            ref = A[:, :Mo].float().t() @ B[:, :No].float()
+            _close(out, 1.0 + (ref.t() if tr else ref), 1e-3, 2e-3 * math.sqrt(K), "tn group %s tr%d" % ((K, Mo, No), tr))
+
+
 # ------------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------------
@@ -306,6 +358,31 @@ def test_attention_fwd_bwd(attn_path, B, H, n, dh):
         a = dqkv[:, w * hid:(w + 1) * hid]
         r = ref_dqkv[:, w * hid:(w + 1) * hid]
         assert _rel_err(a, r) < 2e-2, "%s rel err %.4g" % (nm, _rel_err(a, r))
+
+
+@pytest.mark.parametrize("variant", [10, 11, 12], ids=["big288x256", "big256x256", "big256x160"])
+def test_attention_heads_epilogue_big_tiles(variant):
+    """The per-head scatter epilogue (EPI_HEADS) of the big-tile family: staged through LDS, 16-byte stores,
+    column -> (q/k/v, head, dim) by magic division.  Driven through the attention op (identity GEMM)."""
+    lib = L.lib()
+    lib.fact_debug_gemm_nt_variant(variant)
+    try:
+        for (B, H, n, dh) in [(2, 10, 360, 80), (1, 4, 96, 32), (3, 2, 200, 128)]:
+            hid = H * dh
+            g = torch.Generator(device=DEV).manual_seed(15)
+            qkv = _bf(torch.randn(B * n, 3 * hid, device=DEV, generator=g) * 2.0)
+            dout = _bf(torch.randn(B * n, hid, device=DEV, generator=g))
+            out = torch.full((B * n, hid), float("nan"), device=DEV, dtype=torch.bfloat16)
+            dqkv = torch.full((B * n, 3 * hid), float("nan"), device=DEV, dtype=torch.bfloat16)
+            scratch = torch.empty(lib.fact_op_attention_scratch(B, H, n, dh), device=DEV, dtype=torch.uint8)
+            L.check(lib.fact_op_attention(L.ptr(qkv), B, H, n, dh, hid ** -0.5, L.ptr(out), L.ptr(dout),
+                                          L.ptr(dqkv), L.ptr(scratch), L.cur_stream()))
+            _sync()
+            ref_out, ref_dqkv = _attn_ref(qkv, B, H, n, dh, hid ** -0.5, dout)
+            assert _rel_err(out, ref_out) < 1e-2
+            assert _rel_err(dqkv, ref_dqkv) < 2e-2
+    finally:
+        lib.fact_debug_gemm_nt_variant(0)
 
 
 def test_attention_peaked_softmax(attn_path):

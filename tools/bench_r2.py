@@ -1,0 +1,136 @@
+"""Round-2 GEMM micro-benchmarks (HIP-event timing, one process, interleaved variants):
+  * NT shapes of a FACT cross-modal layer at B = 16: 128x128 kernel vs the round-1 big-tile kernel vs the
+    big-tile family of gemm_big.hip (288x256 / 256x256 / 256x160), each with the epilogue the engine uses;
+  * a layer's four weight gradients: round-1 path (128x128 TN kernel, split-K slabs + reduce, 4 + 4 launches)
+    vs the grouped whole-K launch (160x256 tiles).
+Prints one line per (shape, variant): microseconds, TFLOP/s, relative error vs torch fp32."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mint_amd import _lib as L
+
+lib = L.lib()
+dev = "cuda"
+ITERS = int(os.environ.get("ITERS", "30"))
+
+
+def time_us(fn, iters=ITERS):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+def nt_case(M, N, K, epi, variants, label):
+    g = torch.Generator(device=dev).manual_seed(0)
+    ld = (K + 63) // 64 * 64
+    A = torch.zeros(M, ld, device=dev, dtype=torch.bfloat16)
+    B = torch.zeros(N, ld, device=dev, dtype=torch.bfloat16)
+    A[:, :K] = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+    B[:, :K] = (torch.randn(N, K, device=dev, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g)
+    resid = torch.randn(M, N, device=dev, generator=g)
+    ldn = (N + 63) // 64 * 64
+    pre = torch.randn(M, ldn, device=dev, generator=g).to(torch.bfloat16)
+    f32 = epi in (L.EPI_F32_BIAS_RESID,)
+    o0 = torch.empty(M, N if f32 else ldn, device=dev, dtype=torch.float32 if f32 else torch.bfloat16)
+    o1 = torch.empty(M, ldn, device=dev, dtype=torch.bfloat16)
+    ref = A[:, :K].float() @ B[:, :K].float().t()
+    line = "%-14s M%5d N%5d K%5d:" % (label, M, N, K)
+    for v in variants:
+        lib.fact_debug_gemm_nt_variant(v)
+
+        def launch():
+            L.check(lib.fact_op_gemm_nt(epi, L.ptr(A), ld, L.ptr(B), ld, M, N, K, L.ptr(o0), o0.stride(0), L.ptr(o1),
+                                        ldn, L.ptr(bias), None, 0, L.ptr(resid), N, L.ptr(pre), ldn, L.cur_stream()))
+        us = time_us(launch)
+        if epi == L.EPI_BF16:
+            err = ((o0[:, :N].float() - ref).norm() / ref.norm()).item()
+        elif epi == L.EPI_F32_BIAS_RESID:
+            err = ((o0 - (ref + bias + resid)).norm() / ref.norm()).item()
+        elif epi == L.EPI_BIAS_GELU:
+            err = ((o0[:, :N].float() - (ref + bias)).norm() / ref.norm()).item()
+        else:
+            err = float("nan")
+        line += "  v%-2d %6.1fus %5.0fTF%s" % (v, us, 2.0 * M * N * K / us / 1e6,
+                                              "" if (err < 5e-3 or err != err) else " ERR%.1e" % err)
+    lib.fact_debug_gemm_nt_variant(0)
+    print(line, flush=True)
+
+
+def wgrad_layer(K, d=800, ff=3072):
+    g = torch.Generator(device=dev).manual_seed(1)
+    dp, fp, qp = (d + 63) // 64 * 64, (ff + 63) // 64 * 64, (3 * d + 63) // 64 * 64
+
+    def mk(cols, ld):
+        t = torch.zeros(K, ld, device=dev, dtype=torch.bfloat16)
+        t[:, :cols] = torch.randn(K, cols, device=dev, generator=g).to(torch.bfloat16)
+        return t
+    xin, gact, h2, dpre, att, xmid, h1, dqkv = (mk(d, dp), mk(ff, fp), mk(d, dp), mk(ff, fp), mk(d, dp), mk(d, dp),
+                                                mk(d, dp), mk(3 * d, qp))
+    probs_old = [(gact, ff, xin, d), (h2, d, dpre, ff), (att, d, xmid, d), (h1, d, dqkv, 3 * d)]  # out [Mo][No]
+    outs_old = [torch.zeros(p[1], p[3], device=dev) for p in probs_old]
+    slab = torch.empty(6 * d * max(ff, 3 * d) + 64, device=dev)
+
+    def splitk_for(Mo, No):  # engine rule (engine.hip wgrad())
+        tiles = ((Mo + 127) // 128) * ((No + 127) // 128)
+        sk = max(1, min(6, 560 // tiles, (K + 63) // 64 // 4))
+        return sk
+
+    def old():
+        for (A, Mo, Bm, No), o in zip(probs_old, outs_old):
+            L.check(lib.fact_op_gemm_tn(L.ptr(A), A.stride(0), L.ptr(Bm), Bm.stride(0), Mo, No, K, L.ptr(o), No,
+                                        splitk_for(Mo, No), 2, L.ptr(slab), L.cur_stream()))
+    outs_new = [torch.zeros(ff, d, device=dev), torch.zeros(d, ff, device=dev), torch.zeros(d, d, device=dev),
+                torch.zeros(d, 3 * d, device=dev)]
+    probs_new = [(xin, d, gact, ff, outs_new[0], 1), (h2, d, dpre, ff, outs_new[1], 0),
+                 (att, d, xmid, d, outs_new[2], 0), (h1, d, dqkv, 3 * d, outs_new[3], 0)]
+    n = 4
+    VP, IA = C.c_void_p * n, C.c_int * n
+    a_ = VP(*[p[0].data_ptr() for p in probs_new]); lda = IA(*[p[0].stride(0) for p in probs_new])
+    b_ = VP(*[p[2].data_ptr() for p in probs_new]); ldb = IA(*[p[2].stride(0) for p in probs_new])
+    o_ = VP(*[p[4].data_ptr() for p in probs_new]); ldo = IA(*[p[4].stride(0) for p in probs_new])
+    mo = IA(*[p[1] for p in probs_new]); no = IA(*[p[3] for p in probs_new]); tr = IA(*[p[5] for p in probs_new])
+
+    def new():
+        L.check(lib.fact_op_gemm_tn_group(n, a_, lda, b_, ldb, o_, ldo, mo, no, tr, K, L.cur_stream()))
+    flops = 2.0 * K * (d * ff * 2 + d * d + d * 3 * d)
+    for o in outs_old + outs_new:
+        o.zero_()
+    old(); new()
+    torch.cuda.synchronize()
+    errs = [((outs_new[0].t() - outs_old[0]).norm() / outs_old[0].norm()).item()]
+    errs += [((outs_new[i] - outs_old[i]).norm() / outs_old[i].norm()).item() for i in (1, 2, 3)]
+    t_old, t_new = time_us(old), time_us(new)
+    print("wgrad layer K%5d d%d ff%d: round-1 (4 GEMMs + 4 reduces) %6.1f us %4.0f TF | grouped whole-K %6.1f us %4.0f TF"
+          " | new-vs-old rel diff %s" % (K, d, ff, t_old, flops / t_old / 1e6, t_new, flops / t_new / 1e6,
+                                         " ".join("%.1e" % e for e in errs)), flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "nt"):
+        M = 5760
+        nt_case(M, 3072, 800, L.EPI_BIAS_GELU, [1, 6, 10, 11], "FFN1+gelu")
+        nt_case(M, 3072, 800, L.EPI_GELU_BWD, [1, 6, 10, 11], "dgrad gelu'")
+        nt_case(M, 2400, 800, L.EPI_BF16, [1, 7, 10, 11], "QKV (plain)")
+        nt_case(M, 800, 3072, L.EPI_F32_BIAS_RESID, [1, 12, 11], "FFN2+resid")
+        nt_case(M, 800, 800, L.EPI_F32_BIAS_RESID, [1, 12, 11], "out-proj+resid")
+        nt_case(M, 800, 3072, L.EPI_BF16, [1, 12, 11], "dgrad FFN1")
+        nt_case(M, 800, 2400, L.EPI_BF16, [1, 12, 11], "dgrad QKV")
+        nt_case(M, 800, 800, L.EPI_BF16, [1, 12], "dgrad out-proj")
+        for Me in (3840, 1920):
+            nt_case(Me, 800, 3072, L.EPI_F32_BIAS_RESID, [1, 12], "enc FFN2")
+            nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [1, 6, 10, 11], "enc FFN1")
+        nt_case(8192, 8192, 8192, L.EPI_BF16, [1, 7, 11], "8192^3")
+    if what in ("all", "tn"):
+        for K in (5760, 3840, 1920):
+            wgrad_layer(K)
