@@ -179,6 +179,9 @@ struct FactHandle {
   // Backward scratch that the wgrad stream reads is double-buffered (layer parity) so the dgrad chain
   // only ever waits for the wgrad GEMMs of TWO layers ago, never for the ones just enqueued.
   BwScratch bw[2];  // backward chains: 0 = cross-modal + audio stacks, 1 = motion stack (concurrent)
+  // in-kernel split-K workspaces of the N = 800 GEMMs, one per stream that launches them (caller's / side / aux)
+  float* sk_slab[3] = {nullptr, nullptr, nullptr};
+  unsigned* sk_cnt[3] = {nullptr, nullptr, nullptr};
   hipStream_t aux = nullptr;  // stream of backward chain 1
   // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
   fact_grad_cb cb = nullptr;
@@ -549,6 +552,13 @@ GemmParams gp(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, 
   return p;
 }
 
+// hand the split-K workspace of stream `s` to a GEMM (the dispatcher decides whether to use it)
+void with_ws(FactHandle* h, GemmParams& g, hipStream_t s) {
+  const int i = (s == h->side) ? 1 : (s == h->aux) ? 2 : 0;
+  g.sk_slab = h->sk_slab[i];
+  g.sk_cnt = h->sk_cnt[i];
+}
+
 // dW[Mo][No] += A^T B ; A [K][Mo(lda)], B [K][No(ldb)]
 int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int ldb, int No, int K,
           float* out, int ldo, hipStream_t s, float* slab = nullptr) {
@@ -655,23 +665,27 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
   {
     GemmParams g = gp(a.h1, dp, p.wqkv.t, p.wqkv.ldt, M, 3 * d, d);
     heads_ep(g.ep, st, a.row, 3);
+    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
   CHK(launch_attn_fwd(attn_params(st, a, B), s));
   {
     GemmParams g = gp(a.a, dp, p.wo.t, p.wo.ldt, M, d, d);
     g.ep.out0 = a.x_mid; g.ep.ldo0 = d; g.ep.bias = P(h, p.bo); g.ep.resid = a.x_in; g.ep.ldr = d;
+    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
   CHK(launch_ln_fwd(a.x_mid, P(h, p.ln2_g), P(h, p.ln2_b), a.h2, dp, a.mean2, a.rstd2, M, d, h->cfg.ln_eps, s));
   {
     GemmParams g = gp(a.h2, dp, p.w1.t, p.w1.ldt, M, st.ff, d);
     g.ep.out0 = a.pre; g.ep.ldo0 = fp; g.ep.out1 = a.g; g.ep.ldo1 = fp; g.ep.bias = P(h, p.b1);
+    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_BIAS_GELU, g, s));
   }
   {
     GemmParams g = gp(a.g, fp, p.w2.t, p.w2.ldt, M, d, st.ff);
     g.ep.out0 = a.x_out; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = a.x_mid; g.ep.ldr = d;
+    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
   return 0;
@@ -711,11 +725,13 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   {
     GemmParams g = gp(xin16, dp, p.w2.s, p.w2.lds, M, ff, d);
     g.ep.out0 = dpre; g.ep.ldo0 = fp; g.ep.pre = a.pre; g.ep.ldp = fp;
+    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
   }
   {
     GemmParams g = gp(dpre, fp, p.w1.s, p.w1.lds, M, d, ff);
     g.ep.out0 = sc.dh; g.ep.ldo0 = dp;
+    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
   CHK(launch_ln_bwd(sc.dh, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, G(h, p.ln2_g),
@@ -725,6 +741,7 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
     GemmParams g = gp(xmid16, dp, p.wo.s, p.wo.lds, M, d, d);
     bf16_t* row[1] = {sc.dorow};
     heads_ep(g.ep, st, row, 1);
+    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
   {
@@ -749,6 +766,7 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   {
     GemmParams g = gp(dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
     g.ep.out0 = sc.dh; g.ep.ldo0 = dp;
+    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
   if (two && sc.ev_batch[q ^ 1]) (void)hipStreamWaitEvent(s, sc.ev_batch[q ^ 1], 0);  // readers of xb[q]
@@ -930,6 +948,11 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
   }
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  for (int i = 0; i < 3; ++i) {
+    HIPCHK(hipMalloc((void**)&h->sk_slab[i], kSplitKSlabBytes));
+    HIPCHK(hipMalloc((void**)&h->sk_cnt[i], kSplitKCounters * sizeof(unsigned)));
+    HIPCHK(hipMemset(h->sk_cnt[i], 0, kSplitKCounters * sizeof(unsigned)));
+  }
   h->ev.resize(1024);  // ~170 records per train step: a stored handle is never re-recorded before its use
   for (hipEvent_t& e : h->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *out = h;
@@ -953,6 +976,10 @@ int fact_destroy(FactHandle* h) {
   if (h->opt) (void)hipStreamDestroy(h->opt);
   if (h->aux) (void)hipStreamDestroy(h->aux);
   (void)hipFree(h->ar_motion);
+  for (int i = 0; i < 3; ++i) {
+    (void)hipFree(h->sk_slab[i]);
+    (void)hipFree(h->sk_cnt[i]);
+  }
   delete h;
   return 0;
 }
@@ -1230,6 +1257,18 @@ int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int
   g.ep.bias = bias; g.ep.pos = pos; g.ep.seq = seq; g.ep.resid = resid; g.ep.ldr = ldr;
   g.ep.pre = (const bf16_t*)pre; g.ep.ldp = ldp;
   if (epi == EPI_ATOMIC_F32 && seq > 1) g.splitk = seq;  // bench hook: `seq` carries the K split
+  {  // split-K workspace of the op-level entry (one stream at a time)
+    static float* slab = nullptr;
+    static unsigned* cnt = nullptr;
+    if (!slab) {
+      if (hipMalloc((void**)&slab, kSplitKSlabBytes) != hipSuccess ||
+          hipMalloc((void**)&cnt, kSplitKCounters * sizeof(unsigned)) != hipSuccess)
+        return fail(-20, "split-K workspace alloc");
+      (void)hipMemset(cnt, 0, kSplitKCounters * sizeof(unsigned));
+    }
+    g.sk_slab = slab;
+    g.sk_cnt = cnt;
+  }
   CHK(launch_gemm_nt(epi, g, (hipStream_t)stream));
   return 0;
 }
@@ -1281,6 +1320,10 @@ int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const voi
     q.out = out[i]; q.ldo = ldo[i]; q.M = Mo[i]; q.N = No[i]; q.trans_out = trans[i];
   }
   CHK(launch_big_tn_group(g, (hipStream_t)stream));
+  return 0;
+}
+int fact_debug_gemm_splitk_max(int v) {
+  gemm_set_splitk_max(v);
   return 0;
 }
 int fact_debug_gemm_big_impl(int v) {

@@ -50,8 +50,15 @@ struct GemmParams {
   int splitk;
   int force_generic;  // tests: use the register-staged fallback kernel
   int band;           // NT tile order: band height in m-tiles (0 = default, 1 = row-major)
+  // In-kernel split-K workspace of the big-tile NT kernels (optional): fp32 partial slabs for up to 256
+  // workgroups of one launch and one arrival counter per tile (zero between launches).  One workspace per
+  // stream: launches that may run concurrently must not share it.
+  float* sk_slab;
+  unsigned* sk_cnt;
   EpiParams ep;
 };
+constexpr size_t kSplitKSlabBytes = (size_t)256 * 288 * 256 * 4;  // 256 workgroups x the largest tile, fp32
+constexpr int kSplitKCounters = 1024;
 
 // ---- big-tile family (gemm_big.hip): one 8-wave workgroup per CU, 4-deep LDS-DMA ring -------------------
 enum BigCfgId : int { BIG_288x256 = 0, BIG_256x256 = 1, BIG_256x160 = 2, BIG_160x256 = 3 };
@@ -84,4 +91,5 @@ int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);
 int launch_gemm_tn(int epi, const GemmParams& p, hipStream_t stream);
 void gemm_set_nt_variant(int v);  // 0 auto, 1 = 128x128, 6 / 7 = round-1 big tile, 10 / 11 / 12 = gemm_big.hip configs
 void gemm_set_big_impl(int v);    // auto mode: 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel
+void gemm_set_splitk_max(int v);  // in-kernel split-K of the 256x160 tile: max slices (default 4, 1 = off)
 void gemm_set_nt_band(int band);   // NT tile band height (1 = row-major)

@@ -869,6 +869,7 @@ int g_nt_band = 8;  // tile band height of the 128x128 NT kernel (bench knob; me
 // 10 / 11 / 12 = big-tile family of gemm_big.hip at 288x256 / 256x256 / 256x160 (bench/test knob)
 int g_nt_variant = 0;
 int g_big_impl = 1;  // auto mode: 1 = gemm_big.hip family, 0 = round-1 big kernel (A/B knob)
+int g_splitk_max = 4;  // in-kernel split-K of the 256x160 tile when the caller hands in a workspace (1 = off)
 
 template <int EPI>
 constexpr bool kBigEpi = (EPI == EPI_BF16 || EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_RESID ||
@@ -897,6 +898,7 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
   int variant = g_nt_variant;
   if (p.splitk > 1) variant = 1;
   if constexpr (kBigEpi<EPI>) {
+    const bool ws = p.sk_slab && p.sk_cnt && g_splitk_max > 1 && p.splitk == 1;
     int cfg = -1, old_mr = 0;
     if (variant >= 10 && variant <= 12) cfg = variant - 10;
     else if (variant == 6) old_mr = 9;
@@ -915,9 +917,20 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
       if (e9 >= 0.6 || e8 >= 0.6) {
         if (g_big_impl) cfg = (e8 > e9) ? BIG_256x256 : BIG_288x256;
         else old_mr = (e8 > e9) ? 8 : 9;
-      } else if (g_big_impl && p.N % 160 == 0 && p.N <= 960 && t160 >= 100) {
+      } else if (g_big_impl && p.N % 160 == 0 && p.N <= 960 && (t160 >= 100 || (ws && t160 >= 32))) {
         cfg = BIG_256x160;
       }
+    }
+    if (cfg == BIG_256x160 && ws) {
+      // N = 800 outputs give only 5 column tiles: M = 5760 -> 115 tiles on 256 CUs.  With a workspace each
+      // tile is cut along K into 2-4 slices (<= 256 workgroups) that finish in-kernel.
+      const int t160 = ((p.N + 159) / 160) * ((p.M + 255) / 256);
+      int sk = 256 / t160;
+      if (sk > g_splitk_max) sk = g_splitk_max;
+      // the finish moves 2 x the fp32 tile through L2/fabric (~10 us at 230 workgroups, round-2 bench): it
+      // pays from ~24 stages (768 k) per slice - K = 3072 / 2400 yes, K = 800 no
+      while (sk > 1 && (p.K / 32) / sk < 24) --sk;
+      if (sk > 1) p.splitk = sk;
     }
     if (cfg >= 0 && (EPI != EPI_HEADS || (p.M < 65536 && p.N < 65536))) {
       int bm = 0, bn = 0;
@@ -980,6 +993,7 @@ int check_common(const GemmParams& p, int epi) {
 
 void gemm_set_nt_variant(int v) { g_nt_variant = v; }
 void gemm_set_big_impl(int v) { g_big_impl = v; }
+void gemm_set_splitk_max(int v) { g_splitk_max = v < 1 ? 1 : (v > 4 ? 4 : v); }
 void gemm_set_nt_band(int band) { g_nt_band = band; }
 
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t s) {

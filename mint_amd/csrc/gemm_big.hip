@@ -45,9 +45,11 @@ DEVINL void wait_stages(int stages_after) {
 DEVINL unsigned lds_addr(const unsigned char* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
 }
-DEVINL bf16x4 tr_read0(unsigned addr) {
+template <int OFF>
+DEVINL bf16x4 tr_read(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
   bf16x4 r;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(addr));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
   return r;
 }
 
@@ -89,6 +91,17 @@ struct TnImg {
   static constexpr int N128 = W / 128, TAIL = (W % 128) / 32;
   static_assert(W % 128 == 0 || W % 128 == 32, "TN operand width");
   static constexpr int PIECES = W / 16;
+  // Units (16-column MFMA tiles) of the waves along this operand: wave w of WG owns R units, the first
+  // MAIN of them from the 128-wide sub-images and the rest from the 32-wide tail, so that the hh row
+  // increment of fragment i (256-byte vs 64-byte rows) is a compile-time constant of i.
+  template <int WG, int R>
+  DEVINL static int unit_of(int w, int i) {
+    constexpr int MAIN = 8 * N128 / WG, TAILP = R - MAIN;
+    static_assert((8 * N128) % WG == 0 && TAILP * WG == 2 * TAIL, "unit split");
+    return i < MAIN ? w * MAIN + i : 8 * N128 + w * TAILP + (i - MAIN);
+  }
+  template <int WG, int R>
+  static constexpr int dhh_of(int i) { return i < 8 * N128 / WG ? 4 * 256 : 4 * 64; }
   // source column (relative to the tile) and k row that lane `lane` of DMA piece `p` must fetch
   DEVINL static void piece_src(int p, int lane, int& k, int& col) {
     if (p < N128 * 8) {
@@ -119,36 +132,69 @@ struct TnImg {
   }
 };
 
-// -------------------------------------------------------------------------------------------------
-// Shared main loop.  On entry `src[i]` / `dst[i]` / `adv[i]` describe this wave's DMA pieces (source
-// pointer of stage 0, byte offset inside a stage, elements to advance per stage); on exit acc holds the
-// wave's (MR*16) x (NR*16) sub-tile.  SWAP: swapped MFMA roles (lane owns 4 consecutive n of one m).
-// -------------------------------------------------------------------------------------------------
-template <class C, bool TN, bool SWAP>
-DEVINL void big_mainloop(unsigned char* smem, const bf16_t* (&src)[C::LPS_LO + 1], const int (&dst)[C::LPS_LO + 1],
-                         const size_t (&adv)[C::LPS_LO + 1], int nk, int wave, int wm, int wn, int lane,
-                         f32x4 (&acc)[C::MR][C::NR]) {
-  constexpr int MR = C::MR, NR = C::NR, NSTAGE = C::NSTAGE, DIST = C::DIST;
-  constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
-  const int grp = wave >> 2;  // stagger group: waves 0-3 lead, waves 4-7 run one phase behind
+template <class C, int SO, int PAIR, int J>
+DEVINL void tn_reads_b(const unsigned (&tb)[C::NR][2], bf16x4 (&blo)[C::NR], bf16x4 (&bhi)[C::NR]) {
+  if constexpr (J < C::NR) {
+    constexpr int DH = TnImg<C::BN>::template dhh_of<C::WGN, C::NR>(J);
+    blo[J] = tr_read<SO>(tb[J][PAIR]);
+    bhi[J] = tr_read<SO + DH>(tb[J][PAIR]);
+    tn_reads_b<C, SO, PAIR, J + 1>(tb, blo, bhi);
+  }
+}
+template <class C, int SO, int PAIR, int I>
+DEVINL void tn_reads_a(const unsigned (&ta)[C::MR][2], bf16x4 (&alo)[C::MR], bf16x4 (&ahi)[C::MR]) {
+  if constexpr (I < C::MR) {
+    constexpr int DH = TnImg<C::BM>::template dhh_of<C::WGM, C::MR>(I);
+    alo[I] = tr_read<SO>(ta[I][PAIR]);
+    ahi[I] = tr_read<SO + DH>(ta[I][PAIR]);
+    tn_reads_a<C, SO, PAIR, I + 1>(ta, alo, ahi);
+  }
+}
+// The 2 * (MR + NR) transpose reads of one TN stage: B units first (the multiply needs them for every MFMA).
+template <class C, int SO, int PAIR>
+DEVINL void tn_reads(const unsigned (&ta)[C::MR][2], const unsigned (&tb)[C::NR][2], bf16x4 (&alo)[C::MR],
+                     bf16x4 (&ahi)[C::MR], bf16x4 (&blo)[C::NR], bf16x4 (&bhi)[C::NR]) {
+  tn_reads_b<C, SO, PAIR, 0>(tb, blo, bhi);
+  tn_reads_a<C, SO, PAIR, 0>(ta, alo, ahi);
+}
 
-  auto stage = [&](int kt) {
-    unsigned char* base = smem + (kt % NSTAGE) * C::STAGE_BYTES;
+// -------------------------------------------------------------------------------------------------
+// Shared main loop.  This wave's DMA pieces are described by a wave-uniform source pointer `sptr[i]` (stage 0;
+// advanced by `sadv[i]` bytes per stage with SALU adds), a per-lane byte offset `voff[i]` and the byte offset
+// `dst[i]` inside a stage: the loads are issued in the scalar-base + 32-bit-vector-offset form, no per-lane
+// pointer arithmetic in the loop.  The K loop is unrolled over the NSTAGE = 4 ring slots so that every LDS
+// address is a loop-invariant VGPR plus an IMMEDIATE (ds offset field): the read phase of a wave is nothing
+// but its DMA issues and fragment reads.  Stages past the end of K are still issued (from the last valid
+// stage, into slots nobody reads any more), which makes every wait a constant vmcnt(2 stages).
+// On exit acc holds the wave's sub-tile; SWAP: swapped MFMA roles (lane owns 4 consecutive n of one m).
+// Round-2 PMC on the first version of this loop (per-lane 64-bit pointers, runtime ring slot): 44 VALU + 34
+// SALU beside 20 MFMAs per wave and K step, read phase ~2x the multiply phase, 37 % MFMA busy (TN 160x256).
+// -------------------------------------------------------------------------------------------------
+template <int S>
+struct SlotC { static constexpr int value = S; };
+
+template <class C, bool TN, bool SWAP>
+DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1], const unsigned (&sadv)[C::LPS_LO + 1],
+                         const unsigned (&voff)[C::LPS_LO + 1], const int (&dst)[C::LPS_LO + 1], int nk, int wave,
+                         int wm, int wn, int lane, f32x4 (&acc)[C::MR][C::NR]) {
+  constexpr int MR = C::MR, NR = C::NR, DIST = C::DIST, STAGE = C::STAGE_BYTES;
+  constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
+  static_assert(C::NSTAGE == 4 && DIST == 3, "loop is unrolled over 4 ring slots");
+  const int grp = wave >> 2;  // stagger group: waves 0-3 lead, waves 4-7 run one phase behind
+  const bool extra = EXTRA && wave < EXTRA;
+
+  auto stage = [&](auto slot_c, bool more) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    unsigned char* base = smem + SLOT * STAGE;
 #pragma unroll
-    for (int i = 0; i < LPS_LO; ++i) {
-      glds16(src[i], base + dst[i]);
-      if constexpr (TN) src[i] += adv[i];
-      else src[i] += 32;
-    }
-    if (EXTRA && wave < EXTRA) {
-      glds16(src[LPS_LO], base + dst[LPS_LO]);
-      if constexpr (TN) src[LPS_LO] += adv[LPS_LO];
-      else src[LPS_LO] += 32;
-    }
+    for (int i = 0; i < LPS_LO; ++i) glds16(reinterpret_cast<const bf16_t*>(sptr[i] + voff[i]), base + dst[i]);
+    if (extra) glds16(reinterpret_cast<const bf16_t*>(sptr[LPS_LO] + voff[LPS_LO]), base + dst[LPS_LO]);
+#pragma unroll
+    for (int i = 0; i < LPS_LO + 1; ++i) sptr[i] += more ? sadv[i] : 0u;
   };
-  auto wait_for = [&](int stages_after) {  // wave-uniform: this wave has LPS_LO (+1) loads per stage
-    if (EXTRA && wave < EXTRA) wait_stages<LPS_LO + 1>(stages_after);
-    else wait_stages<LPS_LO>(stages_after);
+  auto wait2 = [&]() {  // at most 2 later stages of this wave stay in flight
+    if (extra) wait_vmcnt<2 * (LPS_LO + 1)>();
+    else wait_vmcnt<2 * LPS_LO>();
   };
 
 #pragma unroll
@@ -156,54 +202,60 @@ DEVINL void big_mainloop(unsigned char* smem, const bf16_t* (&src)[C::LPS_LO + 1
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // TN fragment addressing (per-lane byte offsets inside a stage, hh = 0; dhh = increment to hh = 1)
-  unsigned aoff[MR], boff[NR], adh[MR], bdh[NR];
-  if constexpr (TN) {
+  // loop-invariant fragment addresses
+  unsigned a_nt[4], b_nt[4];              // NT: per ring slot, + i * 1024 immediates
+  unsigned ta[MR][2], tb[NR][2];          // TN: per unit and slot pair {0,1} / {2,3}, + immediates
+  if constexpr (!TN) {
+    const int r = lane & 15, chunk = lane >> 4;
+    const unsigned lanepart = (unsigned)(r * 64 + ((chunk ^ ring_g(r)) << 4));
 #pragma unroll
-    for (int i = 0; i < MR; ++i) TnImg<C::BM>::frag_off(wm * MR + i, lane, aoff[i], adh[i]);
+    for (int sl = 0; sl < 4; ++sl) {
+      a_nt[sl] = (unsigned)(sl * STAGE + wm * MR * 1024) + lanepart;
+      b_nt[sl] = (unsigned)(sl * STAGE + C::A_BYTES + wn * NR * 1024) + lanepart;
+    }
+  } else {
+    const unsigned l0 = lds_addr(smem);
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      unsigned off, dh;
+      TnImg<C::BM>::frag_off(TnImg<C::BM>::template unit_of<C::WGM, MR>(wm, i), lane, off, dh);
+      ta[i][0] = l0 + off;
+      ta[i][1] = l0 + off + 2 * STAGE;
+    }
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-      TnImg<C::BN>::frag_off(wn * NR + j, lane, boff[j], bdh[j]);
-      boff[j] += C::A_BYTES;
+      unsigned off, dh;
+      TnImg<C::BN>::frag_off(TnImg<C::BN>::template unit_of<C::WGN, NR>(wn, j), lane, off, dh);
+      tb[j][0] = l0 + C::A_BYTES + off;
+      tb[j][1] = l0 + C::A_BYTES + off + 2 * STAGE;
     }
   }
 
-#pragma unroll
-  for (int s2 = 0; s2 < DIST; ++s2)
-    if (s2 < nk) stage(s2);
-  wait_for(min(DIST - 1, nk - 1));
+  stage(SlotC<0>{}, 1 < nk);
+  stage(SlotC<1>{}, 2 < nk);
+  stage(SlotC<2>{}, 3 < nk);
+  wait2();
   __builtin_amdgcn_s_barrier();  // stage 0 landed
 
   //   phase 2k   : group 0 stages k+3 and reads k      | group 1 multiplies k-1
   //   phase 2k+1 : group 0 multiplies k                | group 1 stages k+3 and reads k
   // Every wave retires its own pieces of stage k+1 (counted vmcnt) before the barrier that ends phase 2k+1
   // and its fragment reads (lgkmcnt) before the barrier that ends its read phase, so a ring slot is only
-  // re-armed after both groups are done with it (see gemm.hip gemm_nt_big_kernel for the derivation).
+  // re-armed after both groups are done with it (derivation: gemm.hip gemm_nt_big_kernel).
   bf16x8 af[MR], bfr[NR];
-  auto read_frags = [&](int kt) {
-    if (kt + DIST < nk) stage(kt + DIST);
-    const unsigned char* As = smem + (kt % NSTAGE) * C::STAGE_BYTES;
+  auto body = [&](auto slot_c, int kt) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);
     if constexpr (!TN) {
-      const unsigned char* Bs = As + C::A_BYTES;
-      const int chunk = lane >> 4;
 #pragma unroll
-      for (int j = 0; j < NR; ++j) bfr[j] = ring_frag(Bs, wn * (16 * NR) + j * 16 + (lane & 15), chunk);
+      for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + b_nt[SLOT] + j * 1024);
 #pragma unroll
-      for (int i = 0; i < MR; ++i) af[i] = ring_frag(As, wm * (16 * MR) + i * 16 + (lane & 15), chunk);
+      for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_nt[SLOT] + i * 1024);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
-      const unsigned s0 = lds_addr(As);
+      constexpr int SO = (SLOT & 1) * STAGE, PAIR = SLOT / 2;
       bf16x4 blo[NR], bhi[NR], alo[MR], ahi[MR];
-#pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        blo[j] = tr_read0(s0 + boff[j]);
-        bhi[j] = tr_read0(s0 + boff[j] + bdh[j]);
-      }
-#pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        alo[i] = tr_read0(s0 + aoff[i]);
-        ahi[i] = tr_read0(s0 + aoff[i] + adh[i]);
-      }
+      tn_reads<C, SO, PAIR>(ta, tb, alo, ahi, blo, bhi);
       // the asm reads are invisible to hipcc's counters: retire them by hand and pin the order
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -212,8 +264,8 @@ DEVINL void big_mainloop(unsigned char* smem, const bf16_t* (&src)[C::LPS_LO + 1
 #pragma unroll
       for (int i = 0; i < MR; ++i) af[i] = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
     }
-  };
-  auto multiply = [&]() {
+    if (grp == 1) wait2();
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MR; ++i)
@@ -221,17 +273,19 @@ DEVINL void big_mainloop(unsigned char* smem, const bf16_t* (&src)[C::LPS_LO + 1
       for (int j = 0; j < NR; ++j)
         acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
+    if (grp == 0) wait2();
+    __builtin_amdgcn_s_barrier();
   };
   if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one phase behind group 0
-  for (int kt = 0; kt < nk; ++kt) {
-    read_frags(kt);
-    if (grp == 1 && kt + 1 < nk) wait_for(min(DIST - 1, nk - 2 - kt));
-    __builtin_amdgcn_s_barrier();
-    multiply();
-    if (grp == 0 && kt + 1 < nk) wait_for(min(DIST - 1, nk - 2 - kt));
-    __builtin_amdgcn_s_barrier();
+  for (int kt = 0; kt < nk; kt += 4) {
+    body(SlotC<0>{}, kt);
+    if (kt + 1 < nk) body(SlotC<1>{}, kt + 1);
+    if (kt + 2 < nk) body(SlotC<2>{}, kt + 2);
+    if (kt + 3 < nk) body(SlotC<3>{}, kt + 3);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();  // the run-ahead stages past the end of K: landed before the ring is reused for staging
+  __builtin_amdgcn_s_barrier();
 }
 
 // XCD-aware re-deal of the 1-D grid: block b runs on XCD b % 8 (observed); each XCD gets a contiguous
@@ -270,8 +324,11 @@ __global__ __launch_bounds__(512, 1) void big_nt_kernel(const GemmParams p) {
 
   const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM - 1) / BM;
   int m0, n0;
+  // split-K: the slices of a tile are neighbouring logical ids (same XCD, dispatched together)
+  const int lid = xcd_logical_id();
+  const int z = lid % p.splitk, tile = lid / p.splitk;
   {
-    const int id = xcd_logical_id();
+    const int id = tile;
     // bands of `band` m-tiles, m fastest inside a band: the ~32 tiles of an XCD form a near-square patch
     const int band = p.band > 0 ? p.band : 4, per = band * tn;  // host: band_for() (near-square XCD patch)
     const int b = id / per, w = id - b * per;
@@ -279,11 +336,12 @@ __global__ __launch_bounds__(512, 1) void big_nt_kernel(const GemmParams p) {
     m0 = (b * band + w % hb) * BM;
     n0 = (w / hb) * BN;
   }
-  const int nk = p.K / 32;
+  const int nk_all = p.K / 32, nk_per = (nk_all + p.splitk - 1) / p.splitk;
+  const int k_beg = z * nk_per, nk = min(nk_per, nk_all - k_beg);  // host: every slice has >= 1 stage
 
-  const bf16_t* src[C::LPS_LO + 1];
+  const char* sptr[C::LPS_LO + 1];
+  unsigned sadv[C::LPS_LO + 1], voff[C::LPS_LO + 1];
   int dst[C::LPS_LO + 1];
-  size_t adv[C::LPS_LO + 1];
   {
     const int lrow = lane >> 2;                     // row inside the 16-row piece
     const int lchunk = (lane & 3) ^ ring_g(lrow);   // logical 16-byte chunk this lane fetches
@@ -291,18 +349,70 @@ __global__ __launch_bounds__(512, 1) void big_nt_kernel(const GemmParams p) {
     for (int i = 0; i < C::LPS_LO + 1; ++i) {
       const int q = (i < C::LPS_LO) ? wave * C::LPS_LO + i : 8 * C::LPS_LO + wave;  // extras: pieces 8*LPS_LO..
       const int qq = min(q, C::NPIECE - 1);
-      if (qq < C::A_PIECES) {
-        src[i] = p.A + (size_t)min(m0 + qq * 16 + lrow, p.M - 1) * p.lda + lchunk * 8;
+      if (qq < C::A_PIECES) {  // wave-uniform
+        sptr[i] = reinterpret_cast<const char*>(p.A) + (size_t)k_beg * 64;
+        voff[i] = ((unsigned)min(m0 + qq * 16 + lrow, p.M - 1) * (unsigned)p.lda + lchunk * 8) * 2u;
         dst[i] = qq * 1024;
       } else {
-        src[i] = p.B + (size_t)min(n0 + (qq - C::A_PIECES) * 16 + lrow, p.N - 1) * p.ldb + lchunk * 8;
+        sptr[i] = reinterpret_cast<const char*>(p.B) + (size_t)k_beg * 64;
+        voff[i] = ((unsigned)min(n0 + (qq - C::A_PIECES) * 16 + lrow, p.N - 1) * (unsigned)p.ldb + lchunk * 8) * 2u;
         dst[i] = C::A_BYTES + (qq - C::A_PIECES) * 1024;
       }
-      adv[i] = 32;
+      sadv[i] = 64;  // 32 bf16 along K
     }
   }
   f32x4 acc[MR][NR];
-  big_mainloop<C, false, true>(smem, src, dst, adv, nk, wave, wm, wn, lane, acc);
+  big_mainloop<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+
+  if (p.splitk > 1) {
+    // In-launch split-K finish (cdna_hip_programming.md 5 "in-launch split-K reduction", write-through form):
+    // every slice publishes its fp32 partial tile with sc1 (write-through) 16-byte stores in fragment order
+    // (a wave store = 1 KiB contiguous), drains them, and takes a ticket on the tile's arrival counter; the
+    // slice that draws the last ticket adds its peers' partials (sc1 loads behind one agent-scope acquire)
+    // and runs the epilogue.  No spinning: an early slice exits.  Placement-independent; the counter is
+    // returned to zero by the last arriver.
+    constexpr unsigned WG_BYTES = (unsigned)BM * BN * 4;
+    char* tile_slabs = reinterpret_cast<char*>(p.sk_slab) + (size_t)tile * p.splitk * WG_BYTES;
+    const unsigned lane_off = (unsigned)(wave * MR * NR * 1024 + lane * 16);
+    {
+      const __amdgpu_buffer_rsrc_t mine =
+          __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)z * WG_BYTES, 0, WG_BYTES, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), mine,
+                                                 lane_off + (i * NR + j) * 1024, 0, /*sc1*/ 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle: no second __shared__ object
+    if (tid == 0)
+      *flag = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = *flag;
+    if (ticket != (unsigned)(p.splitk - 1)) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int zz = 0; zz < p.splitk; ++zz) {
+      if (zz == z) continue;
+      const __amdgpu_buffer_rsrc_t peer =
+          __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)zz * WG_BYTES, 0, WG_BYTES, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        u32x4 t[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          t[j] = __builtin_amdgcn_raw_buffer_load_b128(peer, lane_off + (i * NR + j) * 1024, 0, /*sc1*/ 16);
+#pragma unroll
+        for (int j = 0; j < NR; ++j) acc[i][j] += __builtin_bit_cast(f32x4, t[j]);
+      }
+    }
+    __syncthreads();  // flag word read by everyone before the ring is reused as epilogue staging
+  }
 
   const EpiParams& ep = p.ep;
   const int wrow0 = m0 + wm * (16 * MR), wcol0 = n0 + wn * (16 * NR);
@@ -549,48 +659,55 @@ __global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
   const int m0 = tmi * BM, n0 = tni * BN;
   const int nk = g.K / 32;
 
-  const bf16_t* src[C::LPS_LO + 1];
+  const char* sptr[C::LPS_LO + 1];
+  unsigned sadv[C::LPS_LO + 1], voff[C::LPS_LO + 1];
   int dst[C::LPS_LO + 1];
-  size_t adv[C::LPS_LO + 1];
 #pragma unroll
   for (int i = 0; i < C::LPS_LO + 1; ++i) {
     const int q = (i < C::LPS_LO) ? wave * C::LPS_LO + i : 8 * C::LPS_LO + wave;
     const int qq = min(q, C::NPIECE - 1);
     int k, col;
-    if (qq < C::A_PIECES) {
+    if (qq < C::A_PIECES) {  // wave-uniform
       TnImg<BM>::piece_src(qq, lane, k, col);
-      src[i] = pr.A + (size_t)k * pr.lda + min(m0 + col, pr.lda - 8);
+      sptr[i] = reinterpret_cast<const char*>(pr.A);
+      voff[i] = ((unsigned)k * (unsigned)pr.lda + (unsigned)min(m0 + col, pr.lda - 8)) * 2u;
       dst[i] = qq * 1024;
-      adv[i] = (size_t)32 * pr.lda;
+      sadv[i] = 64u * (unsigned)pr.lda;  // 32 rows of lda bf16
     } else {
       TnImg<BN>::piece_src(qq - C::A_PIECES, lane, k, col);
-      src[i] = pr.B + (size_t)k * pr.ldb + min(n0 + col, pr.ldb - 8);
+      sptr[i] = reinterpret_cast<const char*>(pr.B);
+      voff[i] = ((unsigned)k * (unsigned)pr.ldb + (unsigned)min(n0 + col, pr.ldb - 8)) * 2u;
       dst[i] = C::A_BYTES + (qq - C::A_PIECES) * 1024;
-      adv[i] = (size_t)32 * pr.ldb;
+      sadv[i] = 64u * (unsigned)pr.ldb;
     }
   }
   f32x4 acc[MR][NR];
-  const int wrow0 = m0 + wm * (16 * MR), wcol0 = n0 + wn * (16 * NR);
+  // output rows / columns of this wave's MFMA tiles (unit order of the TN image: main sub-images, then tail)
+  int mrow[MR], ncol[NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) mrow[i] = m0 + TnImg<BM>::template unit_of<C::WGM, MR>(wm, i) * 16;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) ncol[j] = n0 + TnImg<BN>::template unit_of<C::WGN, NR>(wn, j) * 16;
   if (!pr.trans_out) {
-    big_mainloop<C, true, true>(smem, src, dst, adv, nk, wave, wm, wn, lane, acc);
+    big_mainloop<C, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
     // lane: row m = .. + (lane&15), 4 consecutive n.  All old values are requested before the first store.
     float4 old[MR][NR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
-      const int m = wrow0 + i * 16 + (lane & 15);
+      const int m = mrow[i] + (lane & 15);
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        const int n = wcol0 + j * 16 + (lane >> 4) * 4;
+        const int n = ncol[j] + (lane >> 4) * 4;
         old[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (m < pr.M && n + 3 < pr.N) old[i][j] = *reinterpret_cast<const float4*>(pr.out + (size_t)m * pr.ldo + n);
       }
     }
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
-      const int m = wrow0 + i * 16 + (lane & 15);
+      const int m = mrow[i] + (lane & 15);
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        const int n = wcol0 + j * 16 + (lane >> 4) * 4;
+        const int n = ncol[j] + (lane >> 4) * 4;
         if (m < pr.M && n + 3 < pr.N)
           *reinterpret_cast<float4*>(pr.out + (size_t)m * pr.ldo + n) =
               make_float4(old[i][j].x + acc[i][j][0], old[i][j].y + acc[i][j][1], old[i][j].z + acc[i][j][2],
@@ -598,25 +715,25 @@ __global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
       }
     }
   } else {
-    big_mainloop<C, true, false>(smem, src, dst, adv, nk, wave, wm, wn, lane, acc);
+    big_mainloop<C, true, false>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
     // un-swapped roles: lane holds 4 consecutive m of column n = .. + (lane&15); out is [n][m]
     float4 old[MR][NR];
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
-      const int m = wrow0 + i * 16 + (lane >> 4) * 4;
+      const int m = mrow[i] + (lane >> 4) * 4;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        const int n = wcol0 + j * 16 + (lane & 15);
+        const int n = ncol[j] + (lane & 15);
         old[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (n < pr.N && m + 3 < pr.M) old[i][j] = *reinterpret_cast<const float4*>(pr.out + (size_t)n * pr.ldo + m);
       }
     }
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
-      const int m = wrow0 + i * 16 + (lane >> 4) * 4;
+      const int m = mrow[i] + (lane >> 4) * 4;
 #pragma unroll
       for (int j = 0; j < NR; ++j) {
-        const int n = wcol0 + j * 16 + (lane & 15);
+        const int n = ncol[j] + (lane & 15);
         if (n < pr.N && m + 3 < pr.M)
           *reinterpret_cast<float4*>(pr.out + (size_t)n * pr.ldo + m) =
               make_float4(old[i][j].x + acc[i][j][0], old[i][j].y + acc[i][j][1], old[i][j].z + acc[i][j][2],
@@ -642,7 +759,12 @@ int launch_big_nt_cfg(const GemmParams& p, hipStream_t s) {
     once = true;
   }
   const int tiles = ((p.M + C::BM - 1) / C::BM) * ((p.N + C::BN - 1) / C::BN);
-  hipLaunchKernelGGL((big_nt_kernel<C, EPI>), dim3(tiles), dim3(512), C::LDS_BYTES, s, p);
+  if (p.splitk > 1) {
+    if (!p.sk_slab || !p.sk_cnt || tiles > kSplitKCounters ||
+        (size_t)tiles * p.splitk * C::BM * C::BN * 4 > kSplitKSlabBytes || p.K / 32 / p.splitk < 1)
+      return -9;
+  }
+  hipLaunchKernelGGL((big_nt_kernel<C, EPI>), dim3(tiles * p.splitk), dim3(512), C::LDS_BYTES, s, p);
   return 0;
 }
 
@@ -677,7 +799,8 @@ int big_tile_dims(int cfg, int* bm, int* bn) {
 
 int launch_big_nt(int cfg, int epi, const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
-  if (p.K % 32 || p.K < 32 || p.splitk != 1) return -6;
+  if (p.K % 32 || p.K < 32 || p.splitk < 1 || p.splitk > 4) return -6;
+  if ((size_t)p.M * p.lda >= (1ull << 31) || (size_t)p.N * p.ldb >= (1ull << 31)) return -6;  // 32-bit lane offsets
   if (epi == EPI_HEADS) {
     if (p.M >= 65536 || p.N >= 65536) return -8;
     p.ep.mg_hid = magic_of(p.ep.hid);

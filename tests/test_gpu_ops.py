@@ -141,6 +141,42 @@ def test_gemm_nt_bf16(gemm_path, M, N, K):
     assert _rel_err(out, ref) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(5760, 800, 3072), (1920, 800, 3072), (3840, 800, 800), (700, 800, 2400),
+                                   (5760, 800, 800)])
+def test_gemm_nt_splitk_in_kernel(M, N, K):
+    """256x160 tiles with the in-kernel split-K finish (write-through partial slabs + arrival ticket, last
+    arriver reduces).  The workspace is reused across launches, so every launch gets NEW operands and is
+    checked in full: a stale partial from an earlier launch (missing acquire / cached line) would show."""
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(21)
+    bias = torch.randn(N, device=DEV, generator=g)
+    for it in range(8):
+        A = _bf(torch.randn(M, K, device=DEV, generator=g))
+        B = _bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
+        resid = torch.randn(M, N, device=DEV, generator=g)
+        ref = A.float() @ B.float().t()
+        if it % 2 == 0:
+            o = torch.full((M, N), float("nan"), device=DEV)
+            _gemm_nt(L.EPI_F32_BIAS_RESID, A, B, M, N, K, o, bias=bias, resid=resid)
+            _close(o, ref + bias + resid, 1e-4, 2e-3, "splitk resid it%d" % it)
+        else:
+            o = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+            _gemm_nt(L.EPI_BF16, A, B, M, N, K, o)
+            _close(o, ref, 1e-2, 1e-2 * math.sqrt(K) * 0.1, "splitk bf16 it%d" % it)
+    # same shapes with the split disabled give the same numbers up to fp32 summation order
+    A = _bf(torch.randn(M, K, device=DEV, generator=g))
+    B = _bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
+    o1 = torch.empty(M, N, device=DEV)
+    o2 = torch.empty(M, N, device=DEV)
+    _gemm_nt(L.EPI_F32_BIAS, A, B, M, N, K, o1, bias=bias)
+    lib.fact_debug_gemm_splitk_max(1)
+    try:
+        _gemm_nt(L.EPI_F32_BIAS, A, B, M, N, K, o2, bias=bias)
+    finally:
+        lib.fact_debug_gemm_splitk_max(4)
+    _close(o1, o2, 1e-5, 1e-4, "split vs unsplit")
+
+
 def test_gemm_nt_epilogues(nt_variant):
     M, N, K, seq = 480, 800, 256, 120
     g = torch.Generator(device=DEV).manual_seed(2)

@@ -17,7 +17,8 @@ dev = "cuda"
 ITERS = int(os.environ.get("ITERS", "30"))
 
 
-def time_us(fn, iters=ITERS):
+def time_us(fn, iters=None):
+    iters = iters or ITERS
     for _ in range(3):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -46,7 +47,8 @@ def nt_case(M, N, K, epi, variants, label):
     ref = A[:, :K].float() @ B[:, :K].float().t()
     line = "%-14s M%5d N%5d K%5d:" % (label, M, N, K)
     for v in variants:
-        lib.fact_debug_gemm_nt_variant(v)
+        lib.fact_debug_gemm_splitk_max(1 if v == 112 else 4)   # 112 = 256x160 tiles WITHOUT the in-kernel split-K
+        lib.fact_debug_gemm_nt_variant(12 if v == 112 else v)
 
         def launch():
             L.check(lib.fact_op_gemm_nt(epi, L.ptr(A), ld, L.ptr(B), ld, M, N, K, L.ptr(o0), o0.stride(0), L.ptr(o1),
@@ -63,6 +65,7 @@ def nt_case(M, N, K, epi, variants, label):
         line += "  v%-2d %6.1fus %5.0fTF%s" % (v, us, 2.0 * M * N * K / us / 1e6,
                                               "" if (err < 5e-3 or err != err) else " ERR%.1e" % err)
     lib.fact_debug_gemm_nt_variant(0)
+    lib.fact_debug_gemm_splitk_max(4)
     print(line, flush=True)
 
 
@@ -107,7 +110,7 @@ def wgrad_layer(K, d=800, ff=3072):
         o.zero_()
     old(); new()
     torch.cuda.synchronize()
-    errs = [((outs_new[0].t() - outs_old[0]).norm() / outs_old[0].norm()).item()]
+    errs = [((outs_new[0] - outs_old[0]).norm() / outs_old[0].norm()).item()]
     errs += [((outs_new[i] - outs_old[i]).norm() / outs_old[i].norm()).item() for i in (1, 2, 3)]
     t_old, t_new = time_us(old), time_us(new)
     print("wgrad layer K%5d d%d ff%d: round-1 (4 GEMMs + 4 reduces) %6.1f us %4.0f TF | grouped whole-K %6.1f us %4.0f TF"
@@ -122,15 +125,23 @@ if __name__ == "__main__":
         nt_case(M, 3072, 800, L.EPI_BIAS_GELU, [1, 6, 10, 11], "FFN1+gelu")
         nt_case(M, 3072, 800, L.EPI_GELU_BWD, [1, 6, 10, 11], "dgrad gelu'")
         nt_case(M, 2400, 800, L.EPI_BF16, [1, 7, 10, 11], "QKV (plain)")
-        nt_case(M, 800, 3072, L.EPI_F32_BIAS_RESID, [1, 12, 11], "FFN2+resid")
-        nt_case(M, 800, 800, L.EPI_F32_BIAS_RESID, [1, 12, 11], "out-proj+resid")
-        nt_case(M, 800, 3072, L.EPI_BF16, [1, 12, 11], "dgrad FFN1")
-        nt_case(M, 800, 2400, L.EPI_BF16, [1, 12, 11], "dgrad QKV")
-        nt_case(M, 800, 800, L.EPI_BF16, [1, 12], "dgrad out-proj")
+        nt_case(M, 800, 3072, L.EPI_F32_BIAS_RESID, [1, 112, 12], "FFN2+resid")
+        nt_case(M, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 12], "out-proj+resid")
+        nt_case(M, 800, 3072, L.EPI_BF16, [1, 112, 12], "dgrad FFN1")
+        nt_case(M, 800, 2400, L.EPI_BF16, [1, 112, 12], "dgrad QKV")
+        nt_case(M, 800, 800, L.EPI_BF16, [1, 112, 12], "dgrad out-proj")
         for Me in (3840, 1920):
-            nt_case(Me, 800, 3072, L.EPI_F32_BIAS_RESID, [1, 12], "enc FFN2")
+            nt_case(Me, 800, 3072, L.EPI_F32_BIAS_RESID, [1, 112, 12], "enc FFN2")
+            nt_case(Me, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 12], "enc out-proj")
             nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [1, 6, 10, 11], "enc FFN1")
         nt_case(8192, 8192, 8192, L.EPI_BF16, [1, 7, 11], "8192^3")
+    if what == "pmc":  # few launches of the kernels of interest (for rocprofv3 --pmc passes)
+        ITERS = 4
+        globals()["ITERS"] = 4
+        M = 5760
+        nt_case(M, 3072, 800, L.EPI_BIAS_GELU, [10], "FFN1+gelu")
+        nt_case(M, 800, 3072, L.EPI_BF16, [1, 12], "dgrad FFN1")
+        wgrad_layer(5760)
     if what in ("all", "tn"):
         for K in (5760, 3840, 1920):
             wgrad_layer(K)
