@@ -6,9 +6,20 @@ MFMA compute / fp32 master weights, batch 16 per GPU, AIST++-shaped synthetic te
 
 A step = one pass of the hot path over one batch: forward, MSE loss on 20 target frames, backward,
 RCCL gradient all-reduce (N>1), Keras-Adam update, bf16 weight-shadow refresh.  Prints ONE JSON line
-(rank 0).  `roofline` is for the dominant kernel (the bf16 MFMA GEMM, timed with HIP events on its
-own stream at the cross-modal FFN shape); `cpu_baseline` is the oracle (PyTorch-CPU fp32 restatement
-of the reference train step) timed on this box's host cores at N=1.
+(rank 0) with
+  * `kernels`: every kernel class of the step, timed IN the step (all streams overlapping as usual) with HIP
+    events recorded on the stream each launch goes to (engine option fact_kprof, a few extra steps after the
+    timed region): launches per step, average launch duration, share of the summed kernel time, achieved
+    TFLOP/s or GB/s and the fraction of the bound that applies;
+  * `roofline`: the DOMINANT class of that table (largest time share);
+  * `attention`: the cross-modal attention sub-row the north star names (forward / backward TFLOP/s);
+  * `cpu_baseline`: the oracle (PyTorch-CPU fp32 restatement of the reference train step) timed on this box's
+    host cores at N=1: 1 warm-up + 2 timed steps at batch 4.
+
+Other modes (artefacts for profiles/, not the driver's line):
+  --mode ar      BASELINE.json configs[3] per-GPU share: 32 sequences, 120-frame seed, --steps generated frames
+  --mode scaled  BASELINE.json configs[4]: one full-depth scaled-FACT train step (d=1536, 24 cross layers,
+                 seq 480/960) at --batch sequences
 """
 import argparse
 import json
@@ -33,56 +44,79 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="per-GPU batch (headline: 16)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 16 train, 32 ar, 8 scaled)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-phase timing to stderr")
     ap.add_argument("--side-stream", type=int, default=1, help="0 = single-stream engine (A/B knob)")
     ap.add_argument("--fuse-optimizer", type=int, default=1, help="0 = Adam as a separate pass after backward (A/B knob)")
+    ap.add_argument("--mode", choices=["train", "ar", "scaled"], default="train")
+    ap.add_argument("--profile-steps", type=int, default=4, help="extra steps for the in-step kernel table")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
+                    help="engine option for A/B runs (fact_set_option), e.g. --opt wgrad_parts=1")
     return ap.parse_args()
 
 
-def gemm_roofline(device):
-    """Dominant kernel: the bf16 MFMA NT GEMM with the bias+GELU epilogue (gemm_nt_big_kernel<BIAS_GELU>,
-    288x256 tiles) at the cross-modal FFN1 shape M=5760 (16*360 tokens), N=3072, K=800, operands at the
-    engine's 832-element row pitch.  Algorithmic FLOPs per launch 2*M*N*K = 28.31 GFLOP; timed with HIP
-    events on the stream the kernel is launched on."""
-    from mint_amd import _lib as L
-    lib = L.lib()
-    M, N, K = BATCH_PER_GPU * 360, 3072, 800
-    g = torch.Generator(device=device).manual_seed(0)
-    LD = 832  # bf16 row pitch used by the engine for 800-wide activations / weight shadows
-    A = torch.randn(M, LD, device=device, generator=g).to(torch.bfloat16)
-    B = (torch.randn(N, LD, device=device, generator=g) * 0.05).to(torch.bfloat16)
-    bias = torch.zeros(N, device=device)
-    pre = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-    act = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-    stream = torch.cuda.current_stream()
+PEAK_HBM_GBS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
+# kernel symbols behind each class of the engine's in-step table (for matching against rocprofv3 summaries)
+KERNEL_SYMBOLS = {
+    "wgrad_group": "big_tn_kernel<BigCfg<2,5,4,4>> (160x256 whole-K tiles, grouped: 4 wgrads of a layer)",
+    "ffn1+gelu": "big_nt_kernel<BigCfg<2,9,4,4>, EPI_BIAS_GELU> (288x256 tiles)",
+    "gelu'_dgrad": "big_nt_kernel<BigCfg<2,9,4,4>, EPI_GELU_BWD> (288x256 tiles)",
+    "qkv_gemm+heads": "big_nt_kernel<BigCfg<2,8,4,4>, EPI_HEADS> (256x256 tiles)",
+    "ffn2+resid": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_F32_BIAS_RESID> (256x160 tiles, in-kernel split-K)",
+    "out_proj+resid": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_F32_BIAS_RESID> (256x160 tiles)",
+    "ffn1_dgrad": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_BF16> (256x160 tiles)",
+    "qkv_dgrad": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_BF16> (256x160 tiles)",
+    "out_proj_dgrad+heads": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_HEADS> (256x160 tiles)",
+    "attention_fwd": "attn_fwd_res_kernel<80>", "attention_bwd": "attn_bwd_dq_res_kernel<80> + attn_bwd_dkdv_res_kernel<80>",
+    "ln_fwd": "ln_fwd_kernel", "ln_bwd_dx": "ln_bwd_dx_kernel", "bias/ln_param_grads": "colsum_kernel + ln_param_grads_kernel",
+    "adam+shadows": "adam_fused_kernel",
+}
 
-    def launch():
-        L.check(lib.fact_op_gemm_nt(L.EPI_BIAS_GELU, L.ptr(A), LD, L.ptr(B), LD, M, N, K, L.ptr(pre), N,
-                                    L.ptr(act), N, L.ptr(bias), None, 0, None, 0, None, 0,
-                                    L.cur_stream()))
-    for _ in range(5):
-        launch()
-    iters = 50
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(iters):
-        launch()
-    e1.record(stream)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    flops = 2.0 * M * N * K
-    achieved = flops / (ms * 1e-3) / 1e12
-    traffic = None  # HBM bytes per launch from the committed PMC passes (profiles/roofline_traffic.json)
+
+def kernel_table(model, step_fn, nsteps):
+    """In-step per-kernel-class timing: arm the engine's event recorder, run `nsteps` normal train steps, read
+    the records back.  Durations are what rocprofv3 --kernel-trace reports for the same kernels (events bracket
+    each launch on its own stream); the encoder stacks' launches of a class are averaged in with the cross-modal
+    ones (4 of the 16 layers run at 1/3 and 2/3 of the tokens)."""
+    model.kernel_profile(True)
+    for _ in range(nsteps):
+        step_fn()
+    recs = model.kernel_profile()
+    model.kernel_profile(False)
+    tot = sum(r["total_ms"] for r in recs) or 1.0
+    rows = []
+    for r in recs:
+        if r["launches"] <= 0:
+            continue
+        row = {"name": r["name"], "kernel": KERNEL_SYMBOLS.get(r["name"], r["name"]),
+               "launches_per_step": round(r["launches"] / nsteps, 1),
+               "avg_launch_us": round(r["total_ms"] * 1e3 / r["launches"], 2),
+               "ms_per_step": round(r["total_ms"] / nsteps, 3),
+               "time_share": round(r["total_ms"] / tot, 4)}
+        if r["flops"] > 0:
+            tf = r["flops"] / (r["total_ms"] * 1e-3) / 1e12
+            row.update(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                       frac=round(tf / PEAK_BF16_TFLOPS, 4), flop_per_launch=r["flops"] / r["launches"])
+        else:
+            gbs = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
+            row.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                       frac=round(gbs / PEAK_HBM_GBS, 4), bytes_per_launch=r["bytes"] / r["launches"])
+        rows.append(row)
+    rows.sort(key=lambda x: -x["time_share"])
+    return rows, tot / nsteps
+
+
+def measured_traffic(name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes, with provenance (file +
+    commit); null when the committed profile is for another kernel."""
     try:
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))["traffic_bytes"]
+        t = json.load(open(os.path.join(ROOT, "profiles", "roofline_traffic.json")))
+        if t.get("class") == name:
+            return t.get("traffic_bytes"), t.get("source")
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "gemm_nt_big_kernel<EPI_BIAS_GELU, 9> (288x256 tiles) M5760 N3072 K800",
-            "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "avg_launch_us": round(ms * 1e3, 2),
-            "flop_per_launch": flops, "traffic": traffic}
+    return None, None
 
 
 def usable_cores():
@@ -98,34 +132,118 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(budget_s=25.0):
-    """Oracle (PyTorch-CPU fp32 restatement of the reference train step) on a bounded sample of the
-    same workload: fact_v5 at batch 1.  The forward pass is timed first; the full step (forward,
-    backward, Adam) is only run if it fits the time budget, otherwise the step time is the measured
-    forward time x 3 (backward = 2 x forward FLOPs) and the sample says so."""
+def cpu_baseline(B=4, timed=2):
+    """Oracle (PyTorch-CPU fp32 restatement of the reference train step: forward, loss, backward, Keras Adam)
+    on a bounded sample of the same workload: fact_v5 at batch 4 (a quarter of the per-GPU batch; the fp32 GEMMs
+    of the oracle are large enough at 1440 tokens that frames/s does not depend on the batch), 1 warm-up step
+    + `timed` timed steps on all usable host cores."""
     from oracle import fact_oracle as O
     cores = min(usable_cores(), 64)
     torch.set_num_threads(cores)
     cfg = O.FACT_V5_CFG
-    B = 1
     params = O.init_params(cfg, seed=0, dtype=torch.float32)
     batch = O.synthetic_batch(cfg, B, TARGET_LEN, seed=0, dtype=torch.float32)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        O.fact_forward(params, cfg, batch["motion_input"], batch["audio_input"])
-        t_fwd = time.perf_counter() - t0
-    if 3.5 * t_fwd <= budget_s:
-        m = {k: torch.zeros_like(v) for k, v in params.items()}
-        v = {k: torch.zeros_like(x) for k, x in params.items()}
-        t0 = time.perf_counter()
-        O.train_step(params, m, v, 0, cfg, batch, 1e-4)
-        dt = time.perf_counter() - t0
-        sample = "1 full train step of fact_v5 at batch 1, %.1f s" % dt
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(x) for k, x in params.items()}
+    step = 0
+    t_warm = time.perf_counter()
+    params, m, v = _oracle_step(O, params, m, v, step, cfg, batch)
+    t_warm = time.perf_counter() - t_warm
+    if t_warm > 20.0:  # very slow host: report the warm-up step itself rather than blow the time budget
+        dt, n, note = t_warm, 1, "1 (cold) train step"
     else:
-        dt = 3.0 * t_fwd
-        sample = "forward pass of fact_v5 at batch 1 (%.1f s) x 3 (bwd = 2 x fwd FLOPs); full step over budget" % t_fwd
-    return {"value": round(B * 120 / dt, 2), "unit": "motion frames/sec", "cores": cores, "kind": "port",
-            "sample": sample + " (fp32 PyTorch-CPU oracle, %d threads)" % cores}
+        t0 = time.perf_counter()
+        for i in range(timed):
+            params, m, v = _oracle_step(O, params, m, v, step + 1 + i, cfg, batch)
+        dt, n, note = time.perf_counter() - t0, timed, "1 warm-up + %d timed train steps" % timed
+    return {"value": round(n * B * 120 / dt, 2), "unit": "motion frames/sec", "cores": cores, "kind": "port",
+            "sample": "%s of fact_v5 at batch %d (%.1f s timed; fp32 PyTorch-CPU oracle, %d threads)" % (
+                note, B, dt, cores)}
+
+
+def _oracle_step(O, params, m, v, step, cfg, batch):
+    _loss, _grads, p, m, v = O.train_step(params, m, v, step, cfg, batch, 1e-4)
+    return p, m, v
+
+
+def run_ar(args, device):
+    """BASELINE.json configs[3], per-GPU share: 32 sequences, 120-frame seed, `steps` generated frames each
+    (full forward per frame: no KV cache is possible, fact_model.py:103-132)."""
+    from mint_amd import configs, model_builder
+    B = args.batch or 32
+    steps = args.steps
+    pipe = configs.fact_v5_deeper_t10_cm12()
+    model = model_builder.build(pipe.multi_modal_model, False)
+    gen = torch.Generator().manual_seed(7)
+    inp = {"motion_input": torch.randn(B, 120, 225, generator=gen).to(device),
+           "audio_input": torch.randn(B, 240 + steps - 1, 35, generator=gen).to(device)}
+    model.build(B, 225, 35)
+    model.infer_auto_regressive(inp, steps=min(steps, max(1, args.warmup)))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = model.infer_auto_regressive(inp, steps=steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert out.shape == (B, steps, 225)
+    fwd_flop = 80.97e9 * B  # BASELINE.md section 2, forward FLOPs per sample
+    print(json.dumps({
+        "metric": "generated motion frames/sec (auto-regressive inference) fact_v5_deeper_t10_cm12",
+        "value": round(B * steps / dt, 1), "unit": "generated frames/sec", "n_gpus": 1, "steps": steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "AR inference 120-frame seed -> %d frames (BASELINE.json configs[3], per-GPU share)" % steps,
+                   "per_gpu_batch": B, "audio_frames": 240 + steps - 1},
+        "forward_tflops": round(fwd_flop * steps / dt / 1e12, 1),
+        "forward_mfma_frac": round(fwd_flop * steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4)}))
+
+
+def run_scaled(args, device):
+    """BASELINE.json configs[4]: full-depth scaled FACT (d=1536, 12 heads, ff=6144, 2+2 encoder and 24
+    cross-modal layers, seq 480/960 -> n=1440: tiled attention kernels), train steps at --batch sequences."""
+    from mint_amd import configs, model_builder
+    from mint_amd.trainer import Adam, SingleTaskTrainer
+    B = args.batch or 8
+    mm = configs.fact_config(motion=(480, 225, 1536, 2, 12, 6144), audio=(960, 35, 1536, 2, 12, 6144),
+                             cross=(1536, 24, 12, 6144))
+    model = model_builder.build(mm, True)
+    gen = torch.Generator().manual_seed(9)
+    batch = {"motion_input": torch.randn(B, 480, 225, generator=gen).to(device),
+             "audio_input": torch.randn(B, 960, 35, generator=gen).to(device),
+             "target": torch.randn(B, TARGET_LEN, 225, generator=gen).to(device)}
+    model.build(B, 225, 35)
+    nparams = sum(int(v.numel()) for v in model.trainable_variables)
+
+    class Repeat:
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            return batch
+    tr = SingleTaskTrainer(Repeat(), "target", model, optimizer=Adam(1e-4))
+    it = iter(Repeat())
+    for _ in range(args.warmup):
+        tr.train_step(it)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_step(it)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    d, ff, n = 1536, 6144, 1440
+    lin = lambda tokens, layers: 2.0 * tokens * layers * (4 * d * d + 2 * d * ff)
+    attn = lambda tok, layers: 4.0 * tok * tok * d * layers
+    fwd = (lin(480, 2) + lin(960, 2) + lin(n, 24) + attn(480, 2) + attn(960, 2) + attn(n, 24)
+           + 2.0 * (480 * 225 + 960 * 35 + n * 225) * d)
+    step_flop = 3.0 * fwd * B
+    print(json.dumps({
+        "metric": "motion frames/sec (train step) scaled FACT d=1536 x 24 cross layers",
+        "value": round(B * 480 / dt, 1), "unit": "motion frames/sec", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "scaled FACT train step (BASELINE.json configs[4], per-GPU share)", "per_gpu_batch": B,
+                   "motion_seq": 480, "audio_seq": 960, "hidden": d, "cross_layers": 24, "params": nparams},
+        "step_tflops": round(step_flop / dt / 1e12, 1),
+        "step_mfma_frac": round(step_flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(float(loss), 5)}))
 
 
 def main():
@@ -142,19 +260,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    if args.mode == "ar":
+        return run_ar(args, device)
+    if args.mode == "scaled":
+        return run_scaled(args, device)
     from mint_amd import configs, model_builder
     from mint_amd.learning_schedules import create_learning_rate
     from mint_amd.trainer import Adam, SingleTaskTrainer
 
     pipe = configs.fact_v5_deeper_t10_cm12()
     model = model_builder.build(pipe.multi_modal_model, True)
-    B = args.batch
+    B = args.batch or BATCH_PER_GPU
     gen = torch.Generator().manual_seed(1234 + rank)
     batch = {"motion_input": torch.randn(B, 120, 225, generator=gen).to(device),
              "audio_input": torch.randn(B, 240, 35, generator=gen).to(device),
              "target": torch.randn(B, TARGET_LEN, 225, generator=gen).to(device)}
     model.build(B, 225, 35)
     model.set_option("side_stream", args.side_stream)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        model.set_option(k, int(v))
     opt = Adam(create_learning_rate(pipe.train_config.learning_rate))
 
     class Repeat:
@@ -207,6 +332,7 @@ def main():
             ev[0].elapsed_time(ev[1]) / 5, ev[1].elapsed_time(ev[2]) / 5, ev[2].elapsed_time(ev[3]) / 5),
             file=sys.stderr)
 
+    rows, ksum_ms = kernel_table(model, lambda: trainer.train_step(it), max(1, args.profile_steps))
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         frames_per_s = world * B * 120 / (dt / args.steps)
@@ -225,7 +351,23 @@ def main():
             "step_mfma_frac": round(frames_per_s * FLOP_PER_FRAME / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
         }
-        out["roofline"] = gemm_roofline(device)
+        out["kernels"] = rows
+        top = rows[0]
+        traffic, src = measured_traffic(top["name"])
+        out["roofline"] = {"bound": top["bound"], "kernel": top["kernel"], "class": top["name"],
+                           "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+                           "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"],
+                           "time_share": top["time_share"],
+                           "flop_per_launch": top.get("flop_per_launch"), "traffic": traffic, "traffic_source": src,
+                           "how": "HIP events on the launch stream around every launch of the class, inside normal "
+                                  "train steps (all streams overlapping); sum of kernel-class time per step "
+                                  "%.2f ms vs %.2f ms wall" % (ksum_ms, ms_per_step)}
+        by = {r["name"]: r for r in rows}
+        if "attention_fwd" in by and "attention_bwd" in by:
+            out["attention"] = {
+                "fwd_tflops": by["attention_fwd"]["achieved"], "fwd_mfma_frac": by["attention_fwd"]["frac"],
+                "bwd_tflops": by["attention_bwd"]["achieved"], "bwd_mfma_frac": by["attention_bwd"]["frac"],
+                "note": "QK^T+PV algorithmic FLOPs / in-step launch time, all 16 layers; MFMA-busy PMC: profiles/"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -115,6 +115,15 @@ int fact_adam_bucket(FactHandle* h, int bucket, void* stream);
 /* Disarm a fact_adam_begin whose fact_forward_backward never ran (host-side error): step counter restored. */
 int fact_adam_cancel(FactHandle* h);
 int fact_num_buckets(FactHandle* h, int* n);
+
+/* In-step kernel-class timing.  fact_kprof(h, 1) arms it (and clears earlier records): every instrumented launch
+ * site of the following forward / backward calls is bracketed by HIP events recorded on the stream it launches
+ * on, with all the stream overlap of a normal step.  fact_kprof_read synchronises the device and returns, per
+ * kernel class, the number of launches, the summed event time (ms), the algorithmic FLOPs and bytes.  Measurement
+ * aid of bench.py, not part of the reference surface. */
+int fact_kprof(FactHandle* h, int on);
+int fact_kprof_read(FactHandle* h, int max_classes, int* n_classes, const char** names, double* launches,
+                    double* total_ms, double* flops, double* bytes);
 int fact_get_step(FactHandle* h, int64_t* step);
 int fact_set_step(FactHandle* h, int64_t step);
 

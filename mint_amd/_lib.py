@@ -56,6 +56,9 @@ SIGNATURES = {
     "fact_adam_bucket": (_i, [_vp, _i, _vp]),
     "fact_adam_cancel": (_i, [_vp]),
     "fact_num_buckets": (_i, [_vp, C.POINTER(_i)]),
+    "fact_kprof": (_i, [_vp, _i]),
+    "fact_kprof_read": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fact_get_step": (_i, [_vp, C.POINTER(C.c_int64)]),
     "fact_set_step": (_i, [_vp, C.c_int64]),
     "fact_infer_ar": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), _vp]),

@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -114,15 +115,33 @@ struct AdamArgs {
 // audio stacks use chain 0 on the caller's stream; the motion stack runs at the same time on the handle's
 // third stream with chain 1 (its GEMMs at 1920 tokens fill a fifth of the workgroup slots on their own).
 // Buffers that the wgrad stream reads are double-buffered by layer parity (see layer_backward).
+constexpr int kBwBuf = 3;  // layer-parity depth of every buffer the wgrad stream reads (see layer_backward)
+
+// Work of one layer that only the optimizer waits for (weight / bias / LayerNorm gradients), recorded at the
+// end of the layer's dgrad chain and launched on the wgrad stream a little later (flush_batch).
+struct PendingBatch {
+  bool valid = false;
+  Stack* st = nullptr;
+  int l = 0, M = 0, q = 0;
+  const bf16_t *xin16 = nullptr, *dpre = nullptr, *xmid16 = nullptr, *dqkv = nullptr, *dh2 = nullptr, *dh1 = nullptr;
+  hipStream_t s = nullptr, w = nullptr;
+  float* slab = nullptr;
+};
+
 struct BwScratch {
-  bf16_t* dh = nullptr;      // [M][d pitch] dgrad output feeding the LayerNorm backward
+  bf16_t* dh = nullptr;      // [M][d pitch] dgrad output feeding the LayerNorm backward (fused-kernel path)
   bf16_t* dorow = nullptr;   // per-head dO rows
   float* dsum = nullptr;     // rowsum(dO o O)
-  float* ln_ws = nullptr;    // LayerNorm-backward per-block partial column sums
-  bf16_t *dpre_pp[2] = {nullptr, nullptr}, *dqkv_pp[2] = {nullptr, nullptr};  // [M][ff pitch], [M][3d pitch]
-  bf16_t *xmid_pp[2] = {nullptr, nullptr};  // bf16 gradient at x_mid
-  bf16_t *xb_pp[2] = {nullptr, nullptr};    // bf16 gradient at the layer boundary (output of layer parity q)
-  hipEvent_t ev_batch[2] = {nullptr, nullptr};  // wgrad batch of the last layer of parity q finished
+  float* ln_ws = nullptr;    // LayerNorm-backward per-block partial column sums (fused-kernel path)
+  // buffers both the dgrad chain and the wgrad stream touch, indexed by layer parity q = layer count % 3
+  bf16_t* dpre_pp[kBwBuf] = {};   // [M][ff pitch]
+  bf16_t* dqkv_pp[kBwBuf] = {};   // [M][3d pitch]
+  bf16_t* xmid_pp[kBwBuf] = {};   // bf16 gradient at x_mid
+  bf16_t* xb_pp[kBwBuf] = {};     // bf16 gradient at the layer boundary (output of the layer of parity q)
+  bf16_t* dh2_pp[kBwBuf] = {};    // dgrad outputs feeding the two LayerNorm backward kernels (also read by the
+  bf16_t* dh1_pp[kBwBuf] = {};    //   parameter-gradient column sums on the wgrad stream)
+  hipEvent_t ev_batch[kBwBuf] = {};  // wgrad batch of the last layer of parity q finished
+  PendingBatch pend;
   unsigned bw_i = 0;
   float* slab = nullptr;      // split-K slabs of this chain's wgrad GEMMs (null = the handle's)
   bool inline_wgrad = false;  // run the wgrad batch on the chain's own stream instead of the wgrad stream
@@ -130,8 +149,35 @@ struct BwScratch {
 
 }  // namespace
 
+// In-step kernel-class timing (fact_kprof): HIP events recorded on the launch stream around each instrumented
+// launch site while the train step runs with all its stream overlap; read back per class after a sync.
+enum KClass {
+  KP_LN_FWD, KP_QKV, KP_ATTN_FWD, KP_OUTPROJ, KP_FFN1, KP_FFN2, KP_GELU_DGRAD, KP_DFFN1, KP_LN_BWD, KP_OUT_DGRAD,
+  KP_ATTN_BWD, KP_DQKV, KP_WGRAD, KP_PARAM_GRADS, KP_ADAM, KP_N
+};
+const char* const kKClassName[KP_N] = {
+    "ln_fwd", "qkv_gemm+heads", "attention_fwd", "out_proj+resid", "ffn1+gelu", "ffn2+resid", "gelu'_dgrad",
+    "ffn1_dgrad", "ln_bwd_dx", "out_proj_dgrad+heads", "attention_bwd", "qkv_dgrad", "wgrad_group",
+    "bias/ln_param_grads", "adam+shadows"};
+struct KProf {
+  bool on = false;
+  struct Rec { int cls; int launches; double flops; double bytes; hipEvent_t a, b; };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  size_t used = 0;
+  hipEvent_t get() {
+    if (used == pool.size()) {
+      hipEvent_t e = nullptr;
+      (void)hipEventCreate(&e);
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+};
+
 struct FactHandle {
   FactConfig cfg;
+  KProf kp;
   int max_batch = 0;
   bool training = false;
   bool own_arenas = false;
@@ -170,6 +216,10 @@ struct FactHandle {
   int wgrad_tr = 1;
   int wgrad_slab = 1;
   int wgrad_big = 1;  // whole-K grouped big-tile wgrad launch per layer (gemm_big.hip)
+  int ln_split = 1;   // LayerNorm backward: row-wise dx kernel on the chain, parameter gradients on the wgrad stream
+  int wgrad_parts = 2;   // launches per layer of the grouped wgrad kernel (each ~190/parts workgroups wide)
+  int wgrad_defer = 1;   // release a layer's wgrad batch behind the NEXT layer's GELU' dgrad (240 workgroups)
+  int bwd_splitk = 0;    // in-kernel split-K for the N = 800 dgrad GEMMs (they share the chip with the wgrad launches)
   float* slab = nullptr;  // split-K partial slabs of the wgrad GEMM running on the side stream
   // second stream: wgrad GEMMs run beside the dgrad chain, the audio encoder beside the motion encoder
   int use_side = 1;
@@ -183,6 +233,9 @@ struct FactHandle {
   float* sk_slab[3] = {nullptr, nullptr, nullptr};
   unsigned* sk_cnt[3] = {nullptr, nullptr, nullptr};
   hipStream_t aux = nullptr;  // stream of backward chain 1
+  hipStream_t lite = nullptr; // column-sum kernels of the optimizer-only batches (beside the wgrad launches)
+  int use_lite = 0;  // measured: no gain (round 2), off by default
+  int adam_hold = 1;          // in-backward optimizer: hold the head + cross buckets until the last is final
   // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
   fact_grad_cb cb = nullptr;
   void* cb_user = nullptr;
@@ -191,6 +244,26 @@ struct FactHandle {
 };
 
 namespace {
+
+struct KScope {
+  FactHandle* h;
+  hipStream_t s;
+  size_t idx = (size_t)-1;
+  KScope(FactHandle* h_, int cls, hipStream_t s_, double flops, double bytes = 0, int launches = 1) : h(h_), s(s_) {
+    if (!h->kp.on) return;
+    KProf::Rec r;
+    r.cls = cls; r.launches = launches; r.flops = flops; r.bytes = bytes;
+    r.a = h->kp.get();
+    r.b = h->kp.get();
+    (void)hipEventRecord(r.a, s);
+    idx = h->kp.recs.size();
+    h->kp.recs.push_back(r);
+  }
+  ~KScope() {
+    if (idx != (size_t)-1) (void)hipEventRecord(h->kp.recs[idx].b, s);
+  }
+};
+
 
 // ---------------------------------------------------------------------------------------------
 // parameter table (Keras trainable_variables order: cross_modal_layer, motion_transformer,
@@ -400,11 +473,13 @@ void layout_work(FactHandle* h, Bump& b) {
         lse = lsemax;
       }
       sc.dh = b.take<bf16_t>(Mx * dp);
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < kBwBuf; ++q) {
         sc.dpre_pp[q] = b.take<bf16_t>(Mx * ffmax);
         sc.dqkv_pp[q] = b.take<bf16_t>(Mx * h->cross.qp);
         sc.xmid_pp[q] = b.take<bf16_t>(Mx * dp);
         sc.xb_pp[q] = b.take<bf16_t>(Mx * dp);
+        sc.dh2_pp[q] = b.take<bf16_t>(Mx * dp);
+        sc.dh1_pp[q] = b.take<bf16_t>(Mx * dp);
       }
       sc.dorow = b.take<bf16_t>(rows);
       sc.dsum = b.take<float>(lse);
@@ -532,6 +607,7 @@ int refresh_all(FactHandle* h, hipStream_t s) {
 int adam_bucket(FactHandle* h, int b, hipStream_t s) {
   const Bucket& k = h->buckets[b];
   const AdamArgs& a = h->adam;
+  KScope ks(h, KP_ADAM, s, 0, (double)k.cnt * 36.0);
   if (h->fuse_adam_cast)
     return launch_adam_fused(h->adam_blocks + k.blk_first, k.blk_n, h->params, h->adam_m, h->adam_v, h->grads,
                              a.lr_t, a.b1, a.b2, a.eps, a.gscale, s);
@@ -617,7 +693,7 @@ int wgrad_layer_group(FactHandle* h, const Stack& st, const LayerP& p, const Lay
   set(1, a.h2, st.dp, d, dpre, st.fp, ff, G(h, p.w1.w), ff, 0);         // dW1[d][ff]  = LN2(x)^T dpre
   set(2, a.a, st.dp, d, xmid16, st.dp, d, G(h, p.wo.w), d, 0);          // dWo[d][d]   = attn^T dx_mid
   set(3, a.h1, st.dp, d, dqkv, st.qp, 3 * d, G(h, p.wqkv.w), 3 * d, 0); // dWqkv[d][3d] = LN1(x)^T dqkv
-  CHK(launch_big_tn_group(g, s));
+  CHK(launch_big_tn_group(g, s, h->wgrad_parts));
   return 0;
 }
 
@@ -661,28 +737,42 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
   const int M = B * st.n, d = st.d, dp = st.dp, fp = st.fp;
   LayerP& p = st.lp[l];
   LayerA& a = st.la[l];
-  CHK(launch_ln_fwd(a.x_in, P(h, p.ln1_g), P(h, p.ln1_b), a.h1, dp, a.mean1, a.rstd1, M, d, h->cfg.ln_eps, s));
+  const double Md = (double)M, fl_attn = 4.0 * (double)B * st.H * (double)st.n * st.n * st.dh;
   {
+    KScope k(h, KP_LN_FWD, s, 0, Md * d * 6.0);
+    CHK(launch_ln_fwd(a.x_in, P(h, p.ln1_g), P(h, p.ln1_b), a.h1, dp, a.mean1, a.rstd1, M, d, h->cfg.ln_eps, s));
+  }
+  {
+    KScope k(h, KP_QKV, s, 2.0 * Md * 3 * d * d);
     GemmParams g = gp(a.h1, dp, p.wqkv.t, p.wqkv.ldt, M, 3 * d, d);
     heads_ep(g.ep, st, a.row, 3);
     with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
-  CHK(launch_attn_fwd(attn_params(st, a, B), s));
   {
+    KScope k(h, KP_ATTN_FWD, s, fl_attn);
+    CHK(launch_attn_fwd(attn_params(st, a, B), s));
+  }
+  {
+    KScope k(h, KP_OUTPROJ, s, 2.0 * Md * d * d);
     GemmParams g = gp(a.a, dp, p.wo.t, p.wo.ldt, M, d, d);
     g.ep.out0 = a.x_mid; g.ep.ldo0 = d; g.ep.bias = P(h, p.bo); g.ep.resid = a.x_in; g.ep.ldr = d;
     with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
-  CHK(launch_ln_fwd(a.x_mid, P(h, p.ln2_g), P(h, p.ln2_b), a.h2, dp, a.mean2, a.rstd2, M, d, h->cfg.ln_eps, s));
   {
+    KScope k(h, KP_LN_FWD, s, 0, Md * d * 6.0);
+    CHK(launch_ln_fwd(a.x_mid, P(h, p.ln2_g), P(h, p.ln2_b), a.h2, dp, a.mean2, a.rstd2, M, d, h->cfg.ln_eps, s));
+  }
+  {
+    KScope k(h, KP_FFN1, s, 2.0 * Md * st.ff * d);
     GemmParams g = gp(a.h2, dp, p.w1.t, p.w1.ldt, M, st.ff, d);
     g.ep.out0 = a.pre; g.ep.ldo0 = fp; g.ep.out1 = a.g; g.ep.ldo1 = fp; g.ep.bias = P(h, p.b1);
     with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_BIAS_GELU, g, s));
   }
   {
+    KScope k(h, KP_FFN2, s, 2.0 * Md * st.ff * d);
     GemmParams g = gp(a.g, fp, p.w2.t, p.w2.ldt, M, d, st.ff);
     g.ep.out0 = a.x_out; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = a.x_mid; g.ep.ldr = d;
     with_ws(h, g, s);
@@ -691,18 +781,69 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
   return 0;
 }
 
+// Launch the pending optimizer-only batch of a backward chain on its wgrad stream: the four weight gradients
+// (grouped whole-K launch in `wgrad_parts` pieces), the dense_1 bias and, with the split LayerNorm backward,
+// the LayerNorm / output-bias gradients of both sub-blocks - all behind ONE event recorded on the chain.
+int flush_batch(FactHandle* h, BwScratch& sc) {
+  PendingBatch& b = sc.pend;
+  if (!b.valid) return 0;
+  b.valid = false;
+  Stack& st = *b.st;
+  LayerP& p = st.lp[b.l];
+  LayerA& a = st.la[b.l];
+  const int M = b.M, d = st.d, ff = st.ff, dp = st.dp, fp = st.fp, qp = st.qp;
+  hipStream_t s = b.s, w = b.w;
+  const bool two = (w != s);
+  hipEvent_t rel = two ? stream_after(h, s, w) : nullptr;
+  {
+    KScope k(h, KP_WGRAD, w, 2.0 * (double)M * ((double)d * ff * 2 + (double)d * d * 4), 0,
+             h->wgrad_big ? h->wgrad_parts : 8);
+    const int rc = wgrad_layer_group(h, st, p, a, b.xin16, b.dpre, b.xmid16, b.dqkv, M, w);
+    if (rc < 0) return rc;
+    if (rc > 0) {
+      CHK(wgrad(h, a.g, fp, ff, b.xin16, dp, d, M, G(h, p.w2.w), d, w, b.slab));
+      CHK(wgrad(h, a.h2, dp, d, b.dpre, fp, ff, M, G(h, p.w1.w), ff, w, b.slab));
+      CHK(wgrad(h, a.a, dp, d, b.xmid16, dp, d, M, G(h, p.wo.w), d, w, b.slab));
+      CHK(wgrad(h, a.h1, dp, d, b.dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w, b.slab));
+    }
+  }
+  // the HBM-bound column sums share CUs with anything: their own stream, so they run beside the wgrad launches
+  // instead of behind them (the wgrad stream was as long as the dgrad chain with them in line)
+  hipStream_t c = (two && h->use_lite && h->lite && w == h->side) ? h->lite : w;
+  if (c != w) (void)hipStreamWaitEvent(c, rel, 0);  // same release event as the wgrad launches
+  KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * (ff * 2.0 + d * 16.0), 3);
+  CHK(launch_colsum_bf16(b.dpre, fp, G(h, p.b1), M, ff, ff, c));
+  if (h->ln_split) {
+    // bias gradients of dense_2 / to_out = column sums of the gradient that entered the residual add, taken
+    // from its bf16 copy (xin16 / xmid16); LayerNorm gamma / beta from the dgrad outputs
+    CHK(launch_ln_param_grads(b.dh2, dp, a.x_mid, a.mean2, a.rstd2, b.xin16, dp, 0, G(h, p.ln2_g), G(h, p.ln2_b),
+                              G(h, p.b2), M, d, c));
+    CHK(launch_ln_param_grads(b.dh1, dp, a.x_in, a.mean1, a.rstd1, b.xmid16, dp, 0, G(h, p.ln1_g), G(h, p.ln1_b),
+                              G(h, p.bo), M, d, c));
+  }
+  if (c != w) stream_after(h, c, w);  // the batch marker on the wgrad stream covers both
+  if (two) sc.ev_batch[b.q] = stream_mark(h, w);
+  return 0;
+}
+
 // On entry dx / dx16 hold dL/dx_out of layer l; on exit dL/dx_in (dx in place, dx16 re-pointed to the
 // boundary buffer this layer wrote).
 //
-// Stream plan: the dgrad / attention / LayerNorm chain stays on `s`; the four wgrad GEMMs and the b1 column
-// sum of the layer go to the side stream as ONE batch behind ONE event recorded after the attention
-// backward (an event record costs the recording stream ~7 us of dispatch bubble on MI355X - four per layer
-// were 0.45 ms per step).  Every buffer both streams touch exists twice, indexed by layer parity q:
-//   dpre[q], dqkv[q], xmid[q] : written by this layer, read by this layer's batch; previous writer/readers =
-//                               layer-2 -> the main stream waits for batch(layer-2) at layer entry;
-//   xb[q]                     : this layer's output gradient; it was the INPUT of layer-1, read by
-//                               batch(layer-1) -> waited for just before the last LayerNorm backward.
-// Both waits refer to work enqueued one to two layers earlier, so they are almost always already satisfied.
+// Stream plan (round 2).  The dgrad / attention / LayerNorm chain stays on `s` and is the critical path; what
+// only the optimizer reads (wgrads, bias and LayerNorm gradients) is ONE batch per layer on the wgrad stream.
+// Every big-tile kernel owns its CU (104-136 KiB of LDS), so two of them on different streams exclude each
+// other: a 190-workgroup, 105 us wgrad launch next to the 240-workgroup GELU' dgrad made the latter wait for it
+// (122 us instead of 42, round-2 timeline).  Therefore
+//   * the batch of layer l is released behind the GELU' dgrad of the NEXT layer of the chain (that kernel then
+//     has the chip to itself), and the wgrad launch is cut into `wgrad_parts` = 2 pieces of ~95 workgroups: it
+//     runs beside the narrow rest of the chain (115-160 workgroups: N = 800 dgrads, attention) without
+//     taking CUs from it and is over before the following GELU' dgrad starts;
+//   * every buffer both streams touch exists kBwBuf = 3 times, indexed by layer parity q: the chain only ever
+//     waits for a batch released two to three layers earlier (ev_batch), never for one just enqueued:
+//       dpre[q], dqkv[q], xmid[q], dh2[q], dh1[q] : written by this layer, read by this layer's batch; previous
+//                                  readers = batch(layer+3) -> waited for at layer entry;
+//       xb[q]                    : this layer's output gradient; its previous contents were the INPUT of
+//                                  layer+2, read by batch(layer+2) -> waited for before the last LayerNorm bwd.
 int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& dx16, hipStream_t s,
                    BwScratch& sc) {
   const int M = B * st.n, d = st.d, ff = st.ff, dp = st.dp, fp = st.fp, qp = st.qp;
@@ -713,65 +854,77 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   const bool inl = sc.inline_wgrad && h->wgrad_tr && s == h->aux;
   hipStream_t w = inl ? s : side_of(h, s);
   const bool two = (w != s);
-  float* slab = inl ? sc.slab : nullptr;
-  const int q = (int)(sc.bw_i++ & 1);
+  const int q = (int)(sc.bw_i++ % kBwBuf);
+  const bool split = h->ln_split != 0;
   bf16_t* dpre = sc.dpre_pp[q];
   bf16_t* dqkv = sc.dqkv_pp[q];
   bf16_t* xmid16 = sc.xmid_pp[q];
   bf16_t* xout16 = sc.xb_pp[q];
+  bf16_t* dh2 = split ? sc.dh2_pp[q] : sc.dh;
+  bf16_t* dh1 = split ? sc.dh1_pp[q] : sc.dh;
   const bf16_t* xin16 = dx16;
   if (two && sc.ev_batch[q]) (void)hipStreamWaitEvent(s, sc.ev_batch[q], 0);
   // ---- MLP block: x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
+  const double Md = (double)M, fl_attn = 4.0 * (double)B * st.H * (double)st.n * st.n * st.dh;
   {
+    KScope k(h, KP_GELU_DGRAD, s, 2.0 * Md * ff * d);
     GemmParams g = gp(xin16, dp, p.w2.s, p.w2.lds, M, ff, d);
     g.ep.out0 = dpre; g.ep.ldo0 = fp; g.ep.pre = a.pre; g.ep.ldp = fp;
-    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
   }
+  CHK(flush_batch(h, sc));  // the previous layer's batch: released behind the kernel just enqueued
   {
+    KScope k(h, KP_DFFN1, s, 2.0 * Md * ff * d);
     GemmParams g = gp(dpre, fp, p.w1.s, p.w1.lds, M, d, ff);
-    g.ep.out0 = sc.dh; g.ep.ldo0 = dp;
-    with_ws(h, g, s);
+    g.ep.out0 = dh2; g.ep.ldo0 = dp;
+    if (h->bwd_splitk) with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
-  CHK(launch_ln_bwd(sc.dh, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, G(h, p.ln2_g),
-                    G(h, p.ln2_b), G(h, p.b2), sc.ln_ws, M, d, dp, s));
+  KScope* kln = new KScope(h, KP_LN_BWD, s, 0, Md * d * 16.0);
+  if (split)
+    CHK(launch_ln_bwd_dx(dh2, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, M, d, dp, s));
+  else
+    CHK(launch_ln_bwd(dh2, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, G(h, p.ln2_g),
+                      G(h, p.ln2_b), G(h, p.b2), sc.ln_ws, M, d, dp, s));
+  delete kln;
   // ---- attention block: x_mid = x_in + Wo attn(Wqkv LN1(x_in)) + bo
   {
+    KScope k(h, KP_OUT_DGRAD, s, 2.0 * Md * d * d);
     GemmParams g = gp(xmid16, dp, p.wo.s, p.wo.lds, M, d, d);
     bf16_t* row[1] = {sc.dorow};
     heads_ep(g.ep, st, row, 1);
-    with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
   {
+    KScope k(h, KP_ATTN_BWD, s, 2.5 * fl_attn, 0, 2);
     AttnParams ap = attn_params(st, a, B);
     ap.dorow = sc.dorow; ap.dsum = sc.dsum; ap.dqkv = dqkv;
     CHK(launch_attn_bwd(ap, s));
   }
-  // ---- the layer's weight gradients: one batch on the side stream
-  if (two) stream_after(h, s, w);  // xin16, dpre, xmid16, dqkv are all final
   {
-    const int rc = wgrad_layer_group(h, st, p, a, xin16, dpre, xmid16, dqkv, M, w);
-    if (rc < 0) return rc;
-    if (rc > 0) {
-      CHK(wgrad(h, a.g, fp, ff, xin16, dp, d, M, G(h, p.w2.w), d, w, slab));
-      CHK(wgrad(h, a.h2, dp, d, dpre, fp, ff, M, G(h, p.w1.w), ff, w, slab));
-      CHK(wgrad(h, a.a, dp, d, xmid16, dp, d, M, G(h, p.wo.w), d, w, slab));
-      CHK(wgrad(h, a.h1, dp, d, dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w, slab));
-    }
-  }
-  CHK(launch_colsum_bf16(dpre, fp, G(h, p.b1), M, ff, ff, w));
-  if (two) sc.ev_batch[q] = stream_mark(h, w);
-  {
+    KScope k(h, KP_DQKV, s, 2.0 * Md * 3 * d * d);
     GemmParams g = gp(dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
-    g.ep.out0 = sc.dh; g.ep.ldo0 = dp;
-    with_ws(h, g, s);
+    g.ep.out0 = dh1; g.ep.ldo0 = dp;
+    if (h->bwd_splitk) with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
-  if (two && sc.ev_batch[q ^ 1]) (void)hipStreamWaitEvent(s, sc.ev_batch[q ^ 1], 0);  // readers of xb[q]
-  CHK(launch_ln_bwd(sc.dh, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, G(h, p.ln1_g),
-                    G(h, p.ln1_b), G(h, p.bo), sc.ln_ws, M, d, dp, s));
+  // ---- everything only the optimizer reads: recorded now, released by the next layer (or the caller)
+  {
+    PendingBatch& b = sc.pend;
+    b.valid = true; b.st = &st; b.l = l; b.M = M; b.q = q;
+    b.xin16 = xin16; b.dpre = dpre; b.xmid16 = xmid16; b.dqkv = dqkv; b.dh2 = dh2; b.dh1 = dh1;
+    b.s = s; b.w = w; b.slab = inl ? sc.slab : nullptr;
+    if (!h->wgrad_defer) CHK(flush_batch(h, sc));
+  }
+  // readers of the previous contents of xb[q]: the batch of the layer two steps back
+  const int qr = (q + 1) % kBwBuf;  // parity of layer+2 == parity of layer-1
+  if (two && sc.ev_batch[qr]) (void)hipStreamWaitEvent(s, sc.ev_batch[qr], 0);
+  KScope kln1(h, KP_LN_BWD, s, 0, Md * d * 16.0);
+  if (split)
+    CHK(launch_ln_bwd_dx(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, M, d, dp, s));
+  else
+    CHK(launch_ln_bwd(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, G(h, p.ln1_g),
+                      G(h, p.ln1_b), G(h, p.bo), sc.ln_ws, M, d, dp, s));
   dx16 = xout16;
   return 0;
 }
@@ -792,7 +945,10 @@ int embed_backward(FactHandle* h, Stack& st, int B, float* dx, bf16_t* dx16, hip
   hipStream_t w = inl ? s : side_of(h, s);  // wgrads share the wgrad stream unless the chain keeps its own
   if (w != s) stream_after(h, s, w);
   CHK(wgrad(h, st.xin16, st.featp, st.feat, dx16, st.dp, st.d, M, G(h, st.emb.w), st.d, w, inl ? sc.slab : nullptr));
-  if (w != s) sc.ev_batch[0] = sc.ev_batch[1] = stream_mark(h, w);  // it read the last boundary buffer
+  if (w != s) {  // it read the last boundary buffer
+    hipEvent_t e = stream_mark(h, w);
+    for (int q = 0; q < kBwBuf; ++q) sc.ev_batch[q] = e;
+  }
   CHK(launch_colsum_f32(dx, st.d, G(h, st.emb_b), M, st.d, st.d, s));
   CHK(launch_possum(dx, G(h, st.pos), B, st.n, st.d, s));
   return 0;
@@ -841,8 +997,8 @@ int notify_grads(FactHandle* h, hipStream_t s) {
     // the two small encoder stacks' backward, which leaves most of the chip idle.  The encoder buckets
     // follow as they complete.
     const int last_cross = h->cross.L;  // bucket 0 = head, 1..L = cross layers L-1..0
-    if (b < last_cross) return 0;
-    const int first = (b == last_cross) ? 0 : b;
+    if (h->adam_hold && b < last_cross) return 0;
+    const int first = (h->adam_hold && b == last_cross) ? 0 : b;
     stream_after(h, s, h->opt);
     if (side_of(h, s) != s) stream_after(h, h->side, h->opt);
     for (int i = first; i <= b; ++i) CHK(adam_bucket(h, i, h->opt));
@@ -946,6 +1102,8 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
     int rc2 = build_buckets(h);
     if (rc2) return rc2;
   }
+  // (Stream priorities were tried for the wgrad / column-sum streams in round 2: no gain for the dgrad chain,
+  //  and with a second low-priority stream the step time doubled on this runtime - all streams stay default.)
   HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
   for (int i = 0; i < 3; ++i) {
@@ -975,6 +1133,7 @@ int fact_destroy(FactHandle* h) {
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->opt) (void)hipStreamDestroy(h->opt);
   if (h->aux) (void)hipStreamDestroy(h->aux);
+  if (h->lite) (void)hipStreamDestroy(h->lite);
   (void)hipFree(h->ar_motion);
   for (int i = 0; i < 3; ++i) {
     (void)hipFree(h->sk_slab[i]);
@@ -1028,6 +1187,31 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
   }
   if (!strcmp(key, "wgrad_slab")) {
     h->wgrad_slab = value;
+    return 0;
+  }
+  if (!strcmp(key, "lite_stream")) {
+    if (value && !h->lite) HIPCHK(hipStreamCreateWithFlags(&h->lite, hipStreamNonBlocking));
+    h->use_lite = value;
+    return 0;
+  }
+  if (!strcmp(key, "adam_hold")) {
+    h->adam_hold = value;
+    return 0;
+  }
+  if (!strcmp(key, "wgrad_parts")) {
+    h->wgrad_parts = value < 1 ? 1 : value;
+    return 0;
+  }
+  if (!strcmp(key, "wgrad_defer")) {
+    h->wgrad_defer = value;
+    return 0;
+  }
+  if (!strcmp(key, "bwd_splitk")) {
+    h->bwd_splitk = value;
+    return 0;
+  }
+  if (!strcmp(key, "ln_split")) {
+    h->ln_split = value;
     return 0;
   }
   if (!strcmp(key, "wgrad_big")) {
@@ -1096,8 +1280,11 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   bf16_t* g16 = h->dx16;  // bf16 gradient at the current layer boundary (re-pointed by every layer)
   for (int l = cr.L - 1; l >= 0; --l) {
     CHK(layer_backward(h, cr, l, B, h->dx, g16, s, h->bw[0]));
-    CHK(notify_grads(h, s));  // cross layer l
+    // layer l+1's optimizer-only batch was released inside the call above: its bucket is complete now
+    if (l < cr.L - 1) CHK(notify_grads(h, s));
   }
+  CHK(flush_batch(h, h->bw[0]));
+  if (cr.L > 0) CHK(notify_grads(h, s));  // cross layer 0
   CHK(launch_split_grad(h->dx, B, mo.n, au.n, d, h->dxm, h->dxm16, h->dxa, h->dxa16, cr.dp, s));
   // The two encoder stacks are independent from here on: the motion stack's backward chain runs on the
   // handle's third stream (own scratch, chain 1) beside the audio stack's chain on the caller's stream;
@@ -1109,9 +1296,11 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   //  chain's one-workgroup-per-CU kernels - rocprofv3 timeline, tools/tail_view.py)
   g16 = h->dxa16;
   for (int l = au.L - 1; l >= 0; --l) CHK(layer_backward(h, au, l, B, h->dxa, g16, s, h->bw[0]));
+  CHK(flush_batch(h, h->bw[0]));
   CHK(embed_backward(h, au, B, h->dxa, g16, s, h->bw[0]));
   bf16_t* m16 = h->dxm16;
   for (int l = mo.L - 1; l >= 0; --l) CHK(layer_backward(h, mo, l, B, h->dxm, m16, ms, h->bw[1]));
+  CHK(flush_batch(h, h->bw[1]));
   CHK(embed_backward(h, mo, B, h->dxm, m16, ms, h->bw[1]));
   CHK(notify_grads(h, s));   // audio stack
   CHK(notify_grads(h, ms));  // motion stack
@@ -1122,7 +1311,8 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
     h->adam_pending = false;
   }
   // the caller's stream has joined the side stream: no reader of the backward scratch is left
-  for (BwScratch& sc : h->bw) sc.ev_batch[0] = sc.ev_batch[1] = nullptr;
+  for (BwScratch& sc : h->bw)
+    for (int q = 0; q < kBwBuf; ++q) sc.ev_batch[q] = nullptr;
   return 0;
 }
 
@@ -1186,6 +1376,36 @@ int fact_adam_cancel(FactHandle* h) {
     h->adam_pending = false;
     h->step -= 1;
   }
+  return 0;
+}
+
+int fact_kprof(FactHandle* h, int on) {
+  if (!h) return fail(-1, "null handle");
+  h->kp.on = on != 0;
+  h->kp.recs.clear();
+  h->kp.used = 0;
+  return 0;
+}
+
+int fact_kprof_read(FactHandle* h, int max_classes, int* n_classes, const char** names, double* launches,
+                    double* total_ms, double* flops, double* bytes) {
+  if (!h || !n_classes) return fail(-1, "null argument");
+  HIPCHK(hipDeviceSynchronize());
+  double L[KP_N] = {}, T[KP_N] = {}, F[KP_N] = {}, Bt[KP_N] = {};
+  for (const KProf::Rec& r : h->kp.recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+    L[r.cls] += r.launches; T[r.cls] += ms; F[r.cls] += r.flops; Bt[r.cls] += r.bytes;
+  }
+  const int n = KP_N < max_classes ? KP_N : max_classes;
+  for (int i = 0; i < n; ++i) {
+    if (names) names[i] = kKClassName[i];
+    if (launches) launches[i] = L[i];
+    if (total_ms) total_ms[i] = T[i];
+    if (flops) flops[i] = F[i];
+    if (bytes) bytes[i] = Bt[i];
+  }
+  *n_classes = n;
   return 0;
 }
 
@@ -1341,7 +1561,7 @@ int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const floa
                    const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
                    float* dbeta, float* dbias_prev, int M, int C, void* stream) {
   float* ws = nullptr;
-  if (g_op_ln_ws) {  // bench knob: the engine's partial-sum path (workspace owned by the op)
+  if (g_op_ln_ws == 1) {  // bench knob: the round-1 fused kernel with the partial-sum path (workspace owned by the op)
     static float* buf = nullptr;
     static size_t cap = 0;
     const size_t need = ln_bwd_ws_floats(M, C);
@@ -1351,6 +1571,15 @@ int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const floa
       cap = need;
     }
     ws = buf;
+  }
+  if (g_op_ln_ws == 0 && dgamma && dbeta) {
+    // the engine's form: parameter gradients (here from the fp32 residual gradient, before dx may overwrite it
+    // in place), then the row-wise dx kernel
+    CHK(launch_ln_param_grads((const bf16_t*)dh, C, x, mean, rstd, (dbias_prev ? dres : nullptr), C, 1, dgamma, dbeta,
+                              dbias_prev, M, C, (hipStream_t)stream));
+    CHK(launch_ln_bwd_dx((const bf16_t*)dh, x, mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, M, C, C,
+                         (hipStream_t)stream));
+    return 0;
   }
   CHK(launch_ln_bwd((const bf16_t*)dh, x, mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, dgamma, dbeta,
                     dbias_prev, ws, M, C, C, (hipStream_t)stream));

@@ -83,8 +83,11 @@ struct TnGroup {
   TnProblem p[TN_GROUP_MAX];
   int n;
   int K;
+  int tile0;  // first logical tile of this launch (filled by the launcher)
 };
-int launch_big_tn_group(TnGroup g, hipStream_t stream);
+// `parts` > 1 cuts the group's tiles into that many launches (same stream, in order) of about equal size: each
+// then occupies only ~tiles/parts CUs, which leaves room for the CU-exclusive kernels of another stream.
+int launch_big_tn_group(TnGroup g, hipStream_t stream, int parts = 1);
 
 // Launchers. Return 0 on success, negative on invalid arguments.
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);

@@ -172,6 +172,10 @@ DEVINL void tn_reads(const unsigned (&ta)[C::MR][2], const unsigned (&tb)[C::NR]
 // -------------------------------------------------------------------------------------------------
 template <int S>
 struct SlotC { static constexpr int value = S; };
+#ifndef BIG_DMA_FIRST
+#define BIG_DMA_FIRST 0  // 1 = round-2a order (DMA issues ahead of the fragment reads); A/B build knob
+#endif
+constexpr int DMA_FIRST = BIG_DMA_FIRST;
 
 template <class C, bool TN, bool SWAP>
 DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1], const unsigned (&sadv)[C::LPS_LO + 1],
@@ -245,17 +249,24 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
   bf16x8 af[MR], bfr[NR];
   auto body = [&](auto slot_c, int kt) {
     constexpr int SLOT = decltype(slot_c)::value;
-    stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);
+    if constexpr (DMA_FIRST == 1) stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);
+    // fragment reads first, the DMA issues of stage kt+3 (another ring slot) behind them: the ~60-100 cycles
+    // each LDS-DMA instruction takes to issue then cover the LDS latency of the reads instead of preceding it
     if constexpr (!TN) {
 #pragma unroll
       for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + b_nt[SLOT] + j * 1024);
 #pragma unroll
       for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_nt[SLOT] + i * 1024);
+      if constexpr (DMA_FIRST == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
       constexpr int SO = (SLOT & 1) * STAGE, PAIR = SLOT / 2;
       bf16x4 blo[NR], bhi[NR], alo[MR], ahi[MR];
       tn_reads<C, SO, PAIR>(ta, tb, alo, ahi, blo, bhi);
+      if constexpr (DMA_FIRST == 0) stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);
       // the asm reads are invisible to hipcc's counters: retire them by hand and pin the order
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -644,7 +655,7 @@ __global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / C::WGN, wn = wave % C::WGN;
 
-  const int id = xcd_logical_id();
+  const int id = g.tile0 + xcd_logical_id();
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < TN_GROUP_MAX; ++i)
@@ -821,7 +832,7 @@ int launch_big_nt(int cfg, int epi, const GemmParams& p_in, hipStream_t s) {
 
 // Whole-K grouped wgrad launch.  Every problem: K % 32 == 0, lda / ldb % 8 == 0 and >= 8, out 16-byte
 // aligned with ldo % 4 == 0, M % 4 == 0 and N % 4 == 0.  Fills tiles_m / tile_begin.
-int launch_big_tn_group(TnGroup g, hipStream_t s) {
+int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
   using C = Cfg160x256;
   if (g.n < 1 || g.n > TN_GROUP_MAX || g.K % 32 || g.K < 32) return -1;
   int total = 0;
@@ -838,6 +849,12 @@ int launch_big_tn_group(TnGroup g, hipStream_t s) {
     if (int rc = allow_lds(big_tn_kernel<C>, C::LDS_BYTES)) return rc;
     once = true;
   }
-  hipLaunchKernelGGL((big_tn_kernel<C>), dim3(total), dim3(512), C::LDS_BYTES, s, g);
+  if (parts < 1) parts = 1;
+  for (int i = 0; i < parts; ++i) {
+    const int lo = (int)((long long)total * i / parts), hi = (int)((long long)total * (i + 1) / parts);
+    if (hi <= lo) continue;
+    g.tile0 = lo;
+    hipLaunchKernelGGL((big_tn_kernel<C>), dim3(hi - lo), dim3(512), C::LDS_BYTES, s, g);
+  }
   return 0;
 }

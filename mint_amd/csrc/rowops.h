@@ -22,6 +22,17 @@ int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const flo
                   const float* gamma, const float* dres, float* dx, bf16_t* dx_bf16, float* dgamma,
                   float* dbeta, float* dbias_prev, float* ws, int M, int C, int ld16, hipStream_t s);
 
+// The same backward split by what the dgrad chain waits for (round 2):
+//   launch_ln_bwd_dx        dx = dres + LNbwd(dh) (+ bf16 copy), row-wise, nothing else;
+//   launch_ln_param_grads   dgamma += sum_rows dh*xhat, dbeta += sum_rows dh, dbias += sum_rows dy (dy = the
+//                           gradient that entered the residual add, bf16 [M][ldy] or f32; may be null) - column
+//                           sums only the optimizer needs: the engine queues them on the wgrad stream.
+int launch_ln_bwd_dx(const bf16_t* dh, const float* x, const float* mean, const float* rstd, const float* gamma,
+                     const float* dres, float* dx, bf16_t* dx_bf16, int M, int C, int ld16, hipStream_t s);
+int launch_ln_param_grads(const bf16_t* dh, int ld16, const float* x, const float* mean, const float* rstd,
+                          const void* dy, int ldy, int dy_is_f32, float* dgamma, float* dbeta, float* dbias, int M,
+                          int C, hipStream_t s);
+
 // out[c] += sum_m in[m][c]   (bf16 or f32 input), C % 8 == 0 for bf16, % 4 for f32
 // only columns < Cout are accumulated into out
 int launch_colsum_bf16(const bf16_t* in, int ld, float* out, int M, int C, int Cout, hipStream_t s);

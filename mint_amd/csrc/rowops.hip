@@ -172,6 +172,143 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
   }
 }
 
+// ---- round 2: LayerNorm backward split by what is on the critical path ----------------------------------
+// dx (the residual-stream gradient) is the only output the next kernel of the backward chain waits for; the
+// parameter gradients (dgamma, dbeta, the previous bias) are column sums that only the optimizer reads.
+//   ln_bwd_dx_kernel      row-wise, one wave per row, no column accumulators / LDS / second pass: ~60 VGPRs, so
+//                         its waves fit beside the 184-VGPR wgrad workgroups that run on the same CUs (round-2
+//                         timeline: the fused kernel took 53 us beside the wgrad launch, 20 us alone);
+//   ln_param_grads_kernel column-wise (a lane owns 4 columns, a wave 256), runs on the wgrad stream.
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16_t* __restrict__ dh, const float* __restrict__ x,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ gamma, const float* dres, float* dx,
+                                                        bf16_t* __restrict__ dx16, int M, int C, int ld16) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = C >> 2;
+  const float invC = 1.0f / (float)C;
+  const float mu = mean[row], rs = rstd[row];
+  const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
+  const bf16x4* dhr = reinterpret_cast<const bf16x4*>(dh + (size_t)row * ld16);
+  const float4* rr4 = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * C) : nullptr;
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  float4 xv[MAXV], rv[MAXV], gm[MAXV];
+  bf16x4 dv[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      xv[i] = xr[idx];
+      dv[i] = dhr[idx];
+      rv[i] = rr4 ? rr4[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      gm[i] = g4[idx];
+    }
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      // xv <- xhat, gm <- dy = dh * gamma
+      xv[i] = make_float4((xv[i].x - mu) * rs, (xv[i].y - mu) * rs, (xv[i].z - mu) * rs, (xv[i].w - mu) * rs);
+      gm[i] = make_float4((float)dv[i][0] * gm[i].x, (float)dv[i][1] * gm[i].y, (float)dv[i][2] * gm[i].z,
+                          (float)dv[i][3] * gm[i].w);
+      s1 += (gm[i].x + gm[i].y) + (gm[i].z + gm[i].w);
+      s2 += (gm[i].x * xv[i].x + gm[i].y * xv[i].y) + (gm[i].z * xv[i].z + gm[i].w * xv[i].w);
+    }
+  }
+  s1 = wave_sum(s1) * invC;
+  s2 = wave_sum(s2) * invC;
+  float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * C);
+  bf16x4* dx16r = dx16 ? reinterpret_cast<bf16x4*>(dx16 + (size_t)row * ld16) : nullptr;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float4 o = make_float4(rv[i].x + rs * (gm[i].x - s1 - xv[i].x * s2), rv[i].y + rs * (gm[i].y - s1 - xv[i].y * s2),
+                                   rv[i].z + rs * (gm[i].z - s1 - xv[i].z * s2), rv[i].w + rs * (gm[i].w - s1 - xv[i].w * s2));
+      dxr[idx] = o;
+      if (dx16r) {
+        bf16x4 o16 = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+        dx16r[idx] = o16;
+      }
+    }
+  }
+}
+
+// dgamma[c] += sum_r dh[r][c] * xhat[r][c];  dbeta[c] += sum_r dh[r][c];  dbias[c] += sum_r dy[r][c]
+// grid (ceil(C / 256), ceil(M / rows_per_block)), block 256 = 4 waves; a lane owns 4 consecutive columns, the
+// waves of a block interleave the rows of its chunk; one LDS reduction and 3 atomics per column and block.
+template <typename TY>
+__global__ __launch_bounds__(256) void ln_param_grads_kernel(const bf16_t* __restrict__ dh, int ld16,
+                                                             const float* __restrict__ x,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, const TY* __restrict__ dy,
+                                                             int ldy, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                             int M, int C, int rpb) {
+  __shared__ float red[3][4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 256 + lane * 4;
+  const int r_beg = blockIdx.y * rpb, r_end = min(M, r_beg + rpb);
+  float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f}, ar[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < C) {
+    // 8 rows of this wave per trip, every load of the trip requested before the first use (the kernel has
+    // < 3 waves per CU: bytes in flight per wave, not occupancy, have to cover the HBM latency)
+    constexpr int U = 8;
+    for (int r0 = r_beg + wave; r0 < r_end; r0 += 4 * U) {
+      bf16x4 dv[U];
+      float4 xv[U];
+      float mu[U], rs[U];
+      bf16x4 yb[U];
+      float4 yf[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = min(r0 + 4 * u, M - 1);
+        dv[u] = *reinterpret_cast<const bf16x4*>(dh + (size_t)r * ld16 + c0);
+        xv[u] = *reinterpret_cast<const float4*>(x + (size_t)r * C + c0);
+        mu[u] = mean[r];
+        rs[u] = rstd[r];
+        if (dy) {
+          if constexpr (sizeof(TY) == 2) yb[u] = *reinterpret_cast<const bf16x4*>(dy + (size_t)r * ldy + c0);
+          else yf[u] = *reinterpret_cast<const float4*>(dy + (size_t)r * ldy + c0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (r0 + 4 * u >= r_end) break;
+        const float d0 = (float)dv[u][0], d1 = (float)dv[u][1], d2 = (float)dv[u][2], d3 = (float)dv[u][3];
+        ag[0] += d0 * ((xv[u].x - mu[u]) * rs[u]); ag[1] += d1 * ((xv[u].y - mu[u]) * rs[u]);
+        ag[2] += d2 * ((xv[u].z - mu[u]) * rs[u]); ag[3] += d3 * ((xv[u].w - mu[u]) * rs[u]);
+        ab[0] += d0; ab[1] += d1; ab[2] += d2; ab[3] += d3;
+        if (dy) {
+          if constexpr (sizeof(TY) == 2) {
+            ar[0] += (float)yb[u][0]; ar[1] += (float)yb[u][1]; ar[2] += (float)yb[u][2]; ar[3] += (float)yb[u][3];
+          } else {
+            ar[0] += yf[u].x; ar[1] += yf[u].y; ar[2] += yf[u].z; ar[3] += yf[u].w;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[0][wave][lane * 4 + j] = ag[j];
+    red[1][wave][lane * 4 + j] = ab[j];
+    red[2][wave][lane * 4 + j] = ar[j];
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    const int t = threadIdx.x;
+    atomicAdd(dgamma + c, (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]));
+    atomicAdd(dbeta + c, (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]));
+    if (dy && dbias) atomicAdd(dbias + c, (red[2][0][t] + red[2][1][t]) + (red[2][2][t] + red[2][3][t]));
+  }
+}
+
 // out_k[c] += sum over blocks of part[b][k][c], k = 0..2; grid (ceil(3C/256), ceil(nblk/32))
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int nblk, int C,
                                                         float* __restrict__ o0, float* __restrict__ o1,
@@ -597,6 +734,34 @@ int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const flo
     hipLaunchKernelGGL(colreduce_kernel, g2, dim3(256), 0, s, ws, grid, C, dgamma, dbeta,
                        (dres ? dbias_prev : nullptr));
   }
+  return 0;
+}
+
+int launch_ln_bwd_dx(const bf16_t* dh, const float* x, const float* mean, const float* rstd, const float* gamma,
+                     const float* dres, float* dx, bf16_t* dx_bf16, int M, int C, int ld16, hipStream_t s) {
+  if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0 || ld16 < C || (ld16 & 3)) return -1;
+  const int grid = (M + 3) / 4;
+  if (C <= 1024)
+    hipLaunchKernelGGL((ln_bwd_dx_kernel<4>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
+                       M, C, ld16);
+  else
+    hipLaunchKernelGGL((ln_bwd_dx_kernel<8>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
+                       M, C, ld16);
+  return 0;
+}
+
+int launch_ln_param_grads(const bf16_t* dh, int ld16, const float* x, const float* mean, const float* rstd,
+                          const void* dy, int ldy, int dy_is_f32, float* dgamma, float* dbeta, float* dbias, int M,
+                          int C, hipStream_t s) {
+  if ((C & 3) || M <= 0 || ld16 < C || (ld16 & 3) || (dy && (ldy < C || (ldy & 3)))) return -1;
+  const int rpb = 128;
+  dim3 grid((C + 255) / 256, (M + rpb - 1) / rpb);
+  if (dy_is_f32)
+    hipLaunchKernelGGL((ln_param_grads_kernel<float>), grid, dim3(256), 0, s, dh, ld16, x, mean, rstd, (const float*)dy,
+                       ldy, dgamma, dbeta, dbias, M, C, rpb);
+  else
+    hipLaunchKernelGGL((ln_param_grads_kernel<bf16_t>), grid, dim3(256), 0, s, dh, ld16, x, mean, rstd,
+                       (const bf16_t*)dy, ldy, dgamma, dbeta, dbias, M, C, rpb);
   return 0;
 }
 

@@ -332,6 +332,21 @@ class FACTModel:
         L.check(L.lib().fact_set_grad_callback(self._h, self._grad_cb, None,
                                                C.c_void_p(comm_stream.cuda_stream)))
 
+    def kernel_profile(self, on=None):
+        """In-step kernel-class timing (fact_kprof): `kernel_profile(True)` arms it, `kernel_profile()` reads the
+        records as a list of dicts {name, launches, total_ms, flops, bytes} (device synchronised)."""
+        self._require_built()
+        lib = L.lib()
+        if on is not None:
+            L.check(lib.fact_kprof(self._h, 1 if on else 0))
+            return None
+        n, cap = C.c_int(0), 32
+        names = (C.c_char_p * cap)()
+        arrs = [(C.c_double * cap)() for _ in range(4)]
+        L.check(lib.fact_kprof_read(self._h, cap, C.byref(n), names, *arrs))
+        return [{"name": names[i].decode(), "launches": arrs[0][i], "total_ms": arrs[1][i], "flops": arrs[2][i],
+                 "bytes": arrs[3][i]} for i in range(n.value)]
+
     def set_option(self, key, value):
         self._require_built()
         L.check(L.lib().fact_set_option(self._h, key.encode(), int(value)))

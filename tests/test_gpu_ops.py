@@ -299,8 +299,17 @@ def test_gemm_tn_group_small_dims():
 # ------------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,C", [(64, 128), (1920, 800), (37, 800), (8, 1536)])
-def test_layernorm_fwd_bwd(M, C):
+@pytest.fixture(params=[0, 2], ids=["split", "fused"])
+def ln_bwd_mode(request):
+    """LayerNorm backward as the engine runs it (row-wise dx kernel + column-sum parameter-gradient kernel) and
+    the round-1 fused kernel."""
+    L.lib().fact_debug_ln_bwd(8, request.param)
+    yield request.param
+    L.lib().fact_debug_ln_bwd(8, 0)
+
+
+@pytest.mark.parametrize("M,C", [(64, 128), (1920, 800), (37, 800), (8, 1536), (5760, 800)])
+def test_layernorm_fwd_bwd(ln_bwd_mode, M, C):
     lib = L.lib()
     g = torch.Generator(device=DEV).manual_seed(4)
     x = torch.randn(M, C, device=DEV, generator=g) * 2 + 0.5
