@@ -122,6 +122,7 @@ int fact_num_buckets(FactHandle* h, int* n);
  * kernel class, the number of launches, the summed event time (ms), the algorithmic FLOPs and bytes.  Measurement
  * aid of bench.py, not part of the reference surface. */
 int fact_kprof(FactHandle* h, int on);
+int fact_kprof_dump(FactHandle* h, const char* path); /* CSV timeline: class, stream, start_us, end_us */
 int fact_kprof_read(FactHandle* h, int max_classes, int* n_classes, const char** names, double* launches,
                     double* total_ms, double* flops, double* bytes);
 int fact_get_step(FactHandle* h, int64_t* step);
@@ -193,6 +194,7 @@ int fact_debug_force_generic_gemm(int on);
 int fact_debug_attn_force_tiled(int on);
 /* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 6 / 7 = big-tile 288x256 / 256x256). */
 int fact_debug_gemm_splitk_max(int v); /* in-kernel split-K slices of the N = 800 GEMMs (1 = off, default 4) */
+int fact_debug_gemm_tn_cfg(int v); /* grouped wgrad tile: 0 = 160x256, 1 = 160x384 */
 int fact_debug_gemm_big_impl(int v); /* 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel */
 int fact_debug_gemm_nt_variant(int v);
 /* Test/bench knob: NT GEMM tile band height (tile order inside an XCD; 1 = row-major, default 8). */

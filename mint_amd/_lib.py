@@ -57,6 +57,7 @@ SIGNATURES = {
     "fact_adam_cancel": (_i, [_vp]),
     "fact_num_buckets": (_i, [_vp, C.POINTER(_i)]),
     "fact_kprof": (_i, [_vp, _i]),
+    "fact_kprof_dump": (_i, [_vp, C.c_char_p]),
     "fact_kprof_read": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                              C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "fact_get_step": (_i, [_vp, C.POINTER(C.c_int64)]),
@@ -80,6 +81,7 @@ SIGNATURES = {
     "fact_debug_force_generic_gemm": (_i, [_i]),
     "fact_debug_gemm_nt_variant": (_i, [_i]),
     "fact_debug_gemm_big_impl": (_i, [_i]),
+    "fact_debug_gemm_tn_cfg": (_i, [_i]),
     "fact_debug_gemm_splitk_max": (_i, [_i]),
     "fact_debug_gemm_nt_band": (_i, [_i]),
     "fact_debug_ln_bwd": (_i, [_i, _i]),

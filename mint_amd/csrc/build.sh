@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 OUT=../lib
 mkdir -p "$OUT" "$OUT/obj"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $FACT_EXTRA_FLAGS"
 pids=()
 for f in gemm gemm_big rowops attention engine probe; do
   if [ ! -f "$OUT/obj/$f.o" ] || [ "$f.hip" -nt "$OUT/obj/$f.o" ] || [ -n "$(find . ../../include -name '*.h' -newer "$OUT/obj/$f.o" 2>/dev/null)" ]; then

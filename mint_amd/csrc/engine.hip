@@ -161,7 +161,7 @@ const char* const kKClassName[KP_N] = {
     "bias/ln_param_grads", "adam+shadows"};
 struct KProf {
   bool on = false;
-  struct Rec { int cls; int launches; double flops; double bytes; hipEvent_t a, b; };
+  struct Rec { int cls; int launches; int sid; double flops; double bytes; hipEvent_t a, b; };
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
@@ -253,6 +253,7 @@ struct KScope {
     if (!h->kp.on) return;
     KProf::Rec r;
     r.cls = cls; r.launches = launches; r.flops = flops; r.bytes = bytes;
+    r.sid = (s == h->side) ? 1 : (s == h->aux) ? 2 : (s == h->opt) ? 3 : (s == h->lite) ? 4 : 0;
     r.a = h->kp.get();
     r.b = h->kp.get();
     (void)hipEventRecord(r.a, s);
@@ -811,15 +812,26 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
   // instead of behind them (the wgrad stream was as long as the dgrad chain with them in line)
   hipStream_t c = (two && h->use_lite && h->lite && w == h->side) ? h->lite : w;
   if (c != w) (void)hipStreamWaitEvent(c, rel, 0);  // same release event as the wgrad launches
-  KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * (ff * 2.0 + d * 16.0), 3);
-  CHK(launch_colsum_bf16(b.dpre, fp, G(h, p.b1), M, ff, ff, c));
   if (h->ln_split) {
-    // bias gradients of dense_2 / to_out = column sums of the gradient that entered the residual add, taken
-    // from its bf16 copy (xin16 / xmid16); LayerNorm gamma / beta from the dgrad outputs
-    CHK(launch_ln_param_grads(b.dh2, dp, a.x_mid, a.mean2, a.rstd2, b.xin16, dp, 0, G(h, p.ln2_g), G(h, p.ln2_b),
-                              G(h, p.b2), M, d, c));
-    CHK(launch_ln_param_grads(b.dh1, dp, a.x_in, a.mean1, a.rstd1, b.xmid16, dp, 0, G(h, p.ln1_g), G(h, p.ln1_b),
-                              G(h, p.bo), M, d, c));
+    // ONE launch: the dense_1 bias (column sum of dpre) and, per LayerNorm, gamma / beta from the dgrad output
+    // plus the bias gradient of the GEMM that fed the residual add (dense_2 / to_out) = column sum of the
+    // gradient that entered it, taken from its bf16 copy (xin16 / xmid16)
+    KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * (ff * 2.0 + d * 16.0), 1);
+    ColTasks ts;
+    memset(&ts, 0, sizeof(ts));
+    ts.n = 3;
+    ts.M = M;
+    ts.t[0].dy = b.dpre; ts.t[0].ldy = fp; ts.t[0].dbias = G(h, p.b1); ts.t[0].C = ff;
+    ts.t[1].dh = b.dh2; ts.t[1].ld16 = dp; ts.t[1].x = a.x_mid; ts.t[1].mean = a.mean2; ts.t[1].rstd = a.rstd2;
+    ts.t[1].dy = b.xin16; ts.t[1].ldy = dp; ts.t[1].dgamma = G(h, p.ln2_g); ts.t[1].dbeta = G(h, p.ln2_b);
+    ts.t[1].dbias = G(h, p.b2); ts.t[1].C = d;
+    ts.t[2].dh = b.dh1; ts.t[2].ld16 = dp; ts.t[2].x = a.x_in; ts.t[2].mean = a.mean1; ts.t[2].rstd = a.rstd1;
+    ts.t[2].dy = b.xmid16; ts.t[2].ldy = dp; ts.t[2].dgamma = G(h, p.ln1_g); ts.t[2].dbeta = G(h, p.ln1_b);
+    ts.t[2].dbias = G(h, p.bo); ts.t[2].C = d;
+    CHK(launch_col_tasks(ts, c));
+  } else {
+    KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * ff * 2.0, 1);
+    CHK(launch_colsum_bf16(b.dpre, fp, G(h, p.b1), M, ff, ff, c));
   }
   if (c != w) stream_after(h, c, w);  // the batch marker on the wgrad stream covers both
   if (two) sc.ev_batch[b.q] = stream_mark(h, w);
@@ -1198,6 +1210,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     h->adam_hold = value;
     return 0;
   }
+  if (!strcmp(key, "tn_loop")) {  // process-wide: main loop of the grouped wgrad kernel (gemm_set_tn_cfg)
+    gemm_set_tn_cfg(value);
+    return 0;
+  }
   if (!strcmp(key, "wgrad_parts")) {
     h->wgrad_parts = value < 1 ? 1 : value;
     return 0;
@@ -1409,6 +1425,24 @@ int fact_kprof_read(FactHandle* h, int max_classes, int* n_classes, const char**
   return 0;
 }
 
+/* Timeline dump of the records (CSV: class, stream, start_us, end_us relative to the first record). */
+int fact_kprof_dump(FactHandle* h, const char* path) {
+  if (!h || !path) return fail(-1, "null argument");
+  HIPCHK(hipDeviceSynchronize());
+  FILE* f = fopen(path, "w");
+  if (!f) return fail(-1, "cannot open dump file");
+  if (!h->kp.recs.empty()) {
+    hipEvent_t ref = h->kp.recs[0].a;
+    for (const KProf::Rec& r : h->kp.recs) {
+      float a = 0.f, b = 0.f;
+      if (hipEventElapsedTime(&a, ref, r.a) != hipSuccess || hipEventElapsedTime(&b, ref, r.b) != hipSuccess) continue;
+      fprintf(f, "%s,%d,%.1f,%.1f\n", kKClassName[r.cls], r.sid, a * 1e3, b * 1e3);
+    }
+  }
+  fclose(f);
+  return 0;
+}
+
 int fact_num_buckets(FactHandle* h, int* n) {
   if (!h || !n) return fail(-1, "null argument");
   *n = (int)h->buckets.size();
@@ -1540,6 +1574,10 @@ int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const voi
     q.out = out[i]; q.ldo = ldo[i]; q.M = Mo[i]; q.N = No[i]; q.trans_out = trans[i];
   }
   CHK(launch_big_tn_group(g, (hipStream_t)stream));
+  return 0;
+}
+int fact_debug_gemm_tn_cfg(int v) {
+  gemm_set_tn_cfg(v);
   return 0;
 }
 int fact_debug_gemm_splitk_max(int v) {

@@ -88,6 +88,7 @@ struct TnGroup {
 // `parts` > 1 cuts the group's tiles into that many launches (same stream, in order) of about equal size: each
 // then occupies only ~tiles/parts CUs, which leaves room for the CU-exclusive kernels of another stream.
 int launch_big_tn_group(TnGroup g, hipStream_t stream, int parts = 1);
+void gemm_set_tn_cfg(int v);  // 0 = 160x256 tiles (default), 1 = 160x384 tiles
 
 // Launchers. Return 0 on success, negative on invalid arguments.
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);

@@ -150,6 +150,41 @@ DEVINL void tn_reads_a(const unsigned (&ta)[C::MR][2], bf16x4 (&alo)[C::MR], bf1
     tn_reads_a<C, SO, PAIR, I + 1>(ta, alo, ahi);
   }
 }
+// transpose read number R (0 .. 2*(NR+MR)-1) of a TN stage: B units first, then A units; even R = hh 0, odd = hh 1
+template <class C, int SO, int PAIR, int R>
+DEVINL void tn_read_one(const unsigned (&ta)[C::MR][2], const unsigned (&tb)[C::NR][2], bf16x4 (&alo)[C::MR],
+                        bf16x4 (&ahi)[C::MR], bf16x4 (&blo)[C::NR], bf16x4 (&bhi)[C::NR]) {
+  if constexpr (R < 2 * C::NR) {
+    constexpr int J = R / 2;
+    constexpr int DH = TnImg<C::BN>::template dhh_of<C::WGN, C::NR>(J);
+    if constexpr (R % 2 == 0) blo[J] = tr_read<SO>(tb[J][PAIR]);
+    else bhi[J] = tr_read<SO + DH>(tb[J][PAIR]);
+  } else if constexpr (R < 2 * (C::NR + C::MR)) {
+    constexpr int I = (R - 2 * C::NR) / 2;
+    constexpr int DH = TnImg<C::BM>::template dhh_of<C::WGM, C::MR>(I);
+    if constexpr (R % 2 == 0) alo[I] = tr_read<SO>(ta[I][PAIR]);
+    else ahi[I] = tr_read<SO + DH>(ta[I][PAIR]);
+  }
+}
+DEVINL void mfma16_asm(f32x4& c, bf16x8 a, bf16x8 b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// MFMA number X of a step (row-major over the MR x NR tile) followed by transpose read number X of the next stage
+template <class C, bool SWAP, int SO, int PAIR, int X, int ABL = 0>
+DEVINL void tn_mfma_read_chain(f32x4 (&acc)[C::MR][C::NR], const bf16x8 (&af)[C::MR], const bf16x8 (&bfr)[C::NR],
+                               const unsigned (&ta)[C::MR][2], const unsigned (&tb)[C::NR][2], bf16x4 (&alo)[C::MR],
+                               bf16x4 (&ahi)[C::MR], bf16x4 (&blo)[C::NR], bf16x4 (&bhi)[C::NR]) {
+  if constexpr (X < C::MR * C::NR) {
+    constexpr int I = X / C::NR, J = X % C::NR;
+    if constexpr (ABL != 2) {  // ABL 2: no MFMAs
+      if constexpr (SWAP) mfma16_asm(acc[I][J], bfr[J], af[I]);
+      else mfma16_asm(acc[I][J], af[I], bfr[J]);
+    }
+    if constexpr (ABL != 3) tn_read_one<C, SO, PAIR, X>(ta, tb, alo, ahi, blo, bhi);  // ABL 3: no fragment reads
+    tn_mfma_read_chain<C, SWAP, SO, PAIR, X + 1, ABL>(acc, af, bfr, ta, tb, alo, ahi, blo, bhi);
+  }
+}
+
 // The 2 * (MR + NR) transpose reads of one TN stage: B units first (the multiply needs them for every MFMA).
 template <class C, int SO, int PAIR>
 DEVINL void tn_reads(const unsigned (&ta)[C::MR][2], const unsigned (&tb)[C::NR][2], bf16x4 (&alo)[C::MR],
@@ -296,6 +331,128 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   wait_vmcnt<0>();  // the run-ahead stages past the end of K: landed before the ring is reused for staging
+  __builtin_amdgcn_s_barrier();
+}
+
+// -------------------------------------------------------------------------------------------------
+// TN main loop with FRAGMENT PREFETCH (round 2b).  PMC on the staggered loop above, TN 160x256: the transpose
+// reads deliver 8 bytes per lane, so a wave needs 18 of them per K step and issues one every ~15 cycles
+// (SQ_WAIT_INST_LDS 15 % of wave cycles) - its read phase (~600 cycles) is twice the multiply phase of the
+// other group (320), MFMA busy 44 %.  Here a wave reads the fragments of stage k+1 into a second register set
+// WHILE it multiplies stage k: the reads are off its critical path, the two waves of a SIMD drift apart by
+// themselves (one issues LDS reads while the other issues MFMAs) and one barrier per K step is left:
+//   top of step k : wait for this wave's DMA pieces of stage k+1 (one later stage may stay in flight), barrier
+//   body          : DMA issues of stage k+3 (ring slot of stage k-1, whose reads ended before the barrier),
+//                   transpose reads of stage k+1 -> F[(k+1)&1], 20 MFMAs on F[k&1], lgkmcnt(0)
+// -------------------------------------------------------------------------------------------------
+template <class C, bool SWAP, bool FINE, int ABL = 0>
+DEVINL void tn_mainloop_pf(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1],
+                           const unsigned (&sadv)[C::LPS_LO + 1], const unsigned (&voff)[C::LPS_LO + 1],
+                           const int (&dst)[C::LPS_LO + 1], int nk, int wave, int wm, int wn, int lane,
+                           f32x4 (&acc)[C::MR][C::NR]) {
+  constexpr int MR = C::MR, NR = C::NR, STAGE = C::STAGE_BYTES;
+  constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
+  static_assert(C::NSTAGE == 4, "loop is unrolled over 4 ring slots");
+  const bool extra = EXTRA && wave < EXTRA;
+  auto stage = [&](auto slot_c, bool more) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    unsigned char* base = smem + SLOT * STAGE;
+#pragma unroll
+    for (int i = 0; i < LPS_LO; ++i) glds16(reinterpret_cast<const bf16_t*>(sptr[i] + voff[i]), base + dst[i]);
+    if (extra) glds16(reinterpret_cast<const bf16_t*>(sptr[LPS_LO] + voff[LPS_LO]), base + dst[LPS_LO]);
+#pragma unroll
+    for (int i = 0; i < LPS_LO + 1; ++i) sptr[i] += more ? sadv[i] : 0u;
+  };
+  auto wait1 = [&]() {  // at most 1 later stage of this wave stays in flight
+    if (extra) wait_vmcnt<LPS_LO + 1>();
+    else wait_vmcnt<LPS_LO>();
+  };
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  unsigned ta[MR][2], tb[NR][2];
+  {
+    const unsigned l0 = lds_addr(smem);
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      unsigned off, dh;
+      TnImg<C::BM>::frag_off(TnImg<C::BM>::template unit_of<C::WGM, MR>(wm, i), lane, off, dh);
+      ta[i][0] = l0 + off;
+      ta[i][1] = l0 + off + 2 * STAGE;
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      unsigned off, dh;
+      TnImg<C::BN>::frag_off(TnImg<C::BN>::template unit_of<C::WGN, NR>(wn, j), lane, off, dh);
+      tb[j][0] = l0 + C::A_BYTES + off;
+      tb[j][1] = l0 + C::A_BYTES + off + 2 * STAGE;
+    }
+  }
+  // two fragment register sets
+  bf16x4 alo0[MR], ahi0[MR], blo0[NR], bhi0[NR], alo1[MR], ahi1[MR], blo1[NR], bhi1[NR];
+
+  stage(SlotC<0>{}, 1 < nk);
+  stage(SlotC<1>{}, 2 < nk);
+  stage(SlotC<2>{}, 3 < nk);
+  if (extra) wait_vmcnt<2 * (LPS_LO + 1)>();
+  else wait_vmcnt<2 * LPS_LO>();
+  __builtin_amdgcn_s_barrier();  // stage 0 landed
+  tn_reads<C, 0, 0>(ta, tb, alo0, ahi0, blo0, bhi0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto body = [&](auto slot_c, int kt) {
+    constexpr int SLOT = decltype(slot_c)::value;     // ring slot of stage kt
+    constexpr int NS = (SLOT + 1) & 3;                // ring slot of stage kt + 1
+    constexpr int SO = (NS & 1) * STAGE, PAIR = NS / 2;
+    if constexpr (ABL != 1) wait1();
+    __builtin_amdgcn_s_barrier();
+    if constexpr (ABL != 1) stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);  // ABL 1: no DMA in the loop
+    if constexpr (!FINE) {
+      if constexpr ((SLOT & 1) == 0) tn_reads<C, SO, PAIR>(ta, tb, alo1, ahi1, blo1, bhi1);
+      else tn_reads<C, SO, PAIR>(ta, tb, alo0, ahi0, blo0, bhi0);
+    }
+    bf16x8 af[MR], bfr[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+      bfr[j] = (SLOT & 1) ? __builtin_shufflevector(blo1[j], bhi1[j], 0, 1, 2, 3, 4, 5, 6, 7)
+                          : __builtin_shufflevector(blo0[j], bhi0[j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+      af[i] = (SLOT & 1) ? __builtin_shufflevector(alo1[i], ahi1[i], 0, 1, 2, 3, 4, 5, 6, 7)
+                         : __builtin_shufflevector(alo0[i], ahi0[i], 0, 1, 2, 3, 4, 5, 6, 7);
+    if constexpr (FINE) {
+      // one transpose read of stage k+1 behind every MFMA of stage k (both as asm: program order is issue order)
+      static_assert(2 * (MR + NR) <= MR * NR, "a read slot per MFMA");
+      if constexpr ((SLOT & 1) == 0)
+        tn_mfma_read_chain<C, SWAP, SO, PAIR, 0, ABL>(acc, af, bfr, ta, tb, alo1, ahi1, blo1, bhi1);
+      else
+        tn_mfma_read_chain<C, SWAP, SO, PAIR, 0, ABL>(acc, af, bfr, ta, tb, alo0, ahi0, blo0, bhi0);
+    } else {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+          acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    // the prefetched fragments must have landed before the next step multiplies them (asm reads are
+    // invisible to hipcc's counters) - and before this wave passes the next barrier
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (int kt = 0; kt < nk; kt += 4) {
+    body(SlotC<0>{}, kt);
+    if (kt + 1 < nk) body(SlotC<1>{}, kt + 1);
+    if (kt + 2 < nk) body(SlotC<2>{}, kt + 2);
+    if (kt + 3 < nk) body(SlotC<3>{}, kt + 3);
+  }
+  wait_vmcnt<0>();  // run-ahead stages past the end of K
+  // asm MFMAs: the accumulators are read by the compiler's epilogue code - cover the XDL write-back latency
+  if constexpr (FINE) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   __builtin_amdgcn_s_barrier();
 }
 
@@ -647,7 +804,7 @@ DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f
 // Logical block id -> (problem, m-tile, n-tile), m fastest: with 5 m-tiles per 800-row side the ~24 tiles
 // an XCD owns form a near-square patch (5 x 5 operand panels per K step instead of 24 + 24).
 // -------------------------------------------------------------------------------------------------
-template <class C>
+template <class C, int PF>
 __global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
   constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -700,7 +857,8 @@ __global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
 #pragma unroll
   for (int j = 0; j < NR; ++j) ncol[j] = n0 + TnImg<BN>::template unit_of<C::WGN, NR>(wn, j) * 16;
   if (!pr.trans_out) {
-    big_mainloop<C, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+    if constexpr (PF) tn_mainloop_pf<C, true, PF >= 2, (PF > 2 ? PF - 2 : 0)>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+    else big_mainloop<C, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
     // lane: row m = .. + (lane&15), 4 consecutive n.  All old values are requested before the first store.
     float4 old[MR][NR];
 #pragma unroll
@@ -726,7 +884,8 @@ __global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
       }
     }
   } else {
-    big_mainloop<C, true, false>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+    if constexpr (PF) tn_mainloop_pf<C, false, PF >= 2, (PF > 2 ? PF - 2 : 0)>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+    else big_mainloop<C, true, false>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
     // un-swapped roles: lane holds 4 consecutive m of column n = .. + (lane&15); out is [n][m]
     float4 old[MR][NR];
 #pragma unroll
@@ -832,8 +991,10 @@ int launch_big_nt(int cfg, int epi, const GemmParams& p_in, hipStream_t s) {
 
 // Whole-K grouped wgrad launch.  Every problem: K % 32 == 0, lda / ldb % 8 == 0 and >= 8, out 16-byte
 // aligned with ldo % 4 == 0, M % 4 == 0 and N % 4 == 0.  Fills tiles_m / tile_begin.
-int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
-  using C = Cfg160x256;
+int g_tn_cfg = 0;  // main loop: 0 = staggered wave groups, 1 = fragment prefetch (block), 2 = prefetch interleaved
+
+template <class C, int PF>
+int launch_big_tn_group_t(TnGroup g, hipStream_t s, int parts) {
   if (g.n < 1 || g.n > TN_GROUP_MAX || g.K % 32 || g.K < 32) return -1;
   int total = 0;
   for (int i = 0; i < g.n; ++i) {
@@ -846,7 +1007,7 @@ int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
   }
   static bool once = false;
   if (!once) {
-    if (int rc = allow_lds(big_tn_kernel<C>, C::LDS_BYTES)) return rc;
+    if (int rc = allow_lds(big_tn_kernel<C, PF>, C::LDS_BYTES)) return rc;
     once = true;
   }
   if (parts < 1) parts = 1;
@@ -854,7 +1015,20 @@ int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
     const int lo = (int)((long long)total * i / parts), hi = (int)((long long)total * (i + 1) / parts);
     if (hi <= lo) continue;
     g.tile0 = lo;
-    hipLaunchKernelGGL((big_tn_kernel<C>), dim3(hi - lo), dim3(512), C::LDS_BYTES, s, g);
+    hipLaunchKernelGGL((big_tn_kernel<C, PF>), dim3(hi - lo), dim3(512), C::LDS_BYTES, s, g);
   }
   return 0;
+}
+
+void gemm_set_tn_cfg(int v) { g_tn_cfg = v; }
+
+int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
+  if (g_tn_cfg == 1) return launch_big_tn_group_t<Cfg160x256, 1>(g, s, parts);
+  if (g_tn_cfg == 2) return launch_big_tn_group_t<Cfg160x256, 2>(g, s, parts);
+#ifdef BIG_ABLATION
+  if (g_tn_cfg == 3) return launch_big_tn_group_t<Cfg160x256, 3>(g, s, parts);  // interleaved loop without DMA
+  if (g_tn_cfg == 4) return launch_big_tn_group_t<Cfg160x256, 4>(g, s, parts);  // ... without MFMAs
+  if (g_tn_cfg == 5) return launch_big_tn_group_t<Cfg160x256, 5>(g, s, parts);  // ... without fragment reads
+#endif
+  return launch_big_tn_group_t<Cfg160x256, 0>(g, s, parts);
 }

@@ -33,6 +33,29 @@ int launch_ln_param_grads(const bf16_t* dh, int ld16, const float* x, const floa
                           const void* dy, int ldy, int dy_is_f32, float* dgamma, float* dbeta, float* dbias, int M,
                           int C, hipStream_t s);
 
+// Up to 3 column-sum tasks over the same M rows in one launch: x != null -> LayerNorm parameter gradients of
+// (dh, x, mean, rstd) plus dbias += colsum(dy) when dy is given; x == null -> dbias += colsum(dy) only.
+constexpr int COL_TASKS_MAX = 3;
+struct ColTask {
+  const bf16_t* dh;
+  int ld16;
+  const float* x;
+  const float* mean;
+  const float* rstd;
+  const bf16_t* dy;
+  int ldy;
+  float* dgamma;
+  float* dbeta;
+  float* dbias;
+  int C;
+  int cg_begin;  // filled by the launcher
+};
+struct ColTasks {
+  ColTask t[COL_TASKS_MAX];
+  int n, M, rpb;
+};
+int launch_col_tasks(ColTasks ts, hipStream_t s);
+
 // out[c] += sum_m in[m][c]   (bf16 or f32 input), C % 8 == 0 for bf16, % 4 for f32
 // only columns < Cout are accumulated into out
 int launch_colsum_bf16(const bf16_t* in, int ld, float* out, int M, int C, int Cout, hipStream_t s);

@@ -309,6 +309,75 @@ __global__ __launch_bounds__(256) void ln_param_grads_kernel(const bf16_t* __res
   }
 }
 
+// All column sums of one layer's optimizer-only batch in ONE launch (ColTasks): per task either the LayerNorm
+// parameter gradients (+ the bias gradient from dy) as above, or a plain column sum of dy (x == nullptr).
+// grid (total column groups of 256, ceil(M / rpb)).
+__global__ __launch_bounds__(256) void col_tasks_kernel(const ColTasks ts) {
+  __shared__ float red[3][4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int ti = 0;
+#pragma unroll
+  for (int i = 1; i < COL_TASKS_MAX; ++i)
+    if (i < ts.n && (int)blockIdx.x >= ts.t[i].cg_begin) ti = i;
+  ColTask t = ts.t[0];
+#pragma unroll
+  for (int i = 1; i < COL_TASKS_MAX; ++i)
+    if (ti == i) t = ts.t[i];
+  const int cg = blockIdx.x - t.cg_begin;
+  const int c0 = cg * 256 + lane * 4;
+  const int r_beg = blockIdx.y * ts.rpb, r_end = min(ts.M, r_beg + ts.rpb);
+  const bool ln = t.x != nullptr;
+  float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f}, ar[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c0 < t.C) {
+    constexpr int U = 8;
+    for (int r0 = r_beg + wave; r0 < r_end; r0 += 4 * U) {
+      bf16x4 dv[U], yb[U];
+      float4 xv[U];
+      float mu[U], rs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = min(r0 + 4 * u, ts.M - 1);
+        if (ln) {
+          dv[u] = *reinterpret_cast<const bf16x4*>(t.dh + (size_t)r * t.ld16 + c0);
+          xv[u] = *reinterpret_cast<const float4*>(t.x + (size_t)r * t.C + c0);
+          mu[u] = t.mean[r];
+          rs[u] = t.rstd[r];
+        }
+        if (t.dy) yb[u] = *reinterpret_cast<const bf16x4*>(t.dy + (size_t)r * t.ldy + c0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (r0 + 4 * u >= r_end) break;
+        if (ln) {
+          const float d0 = (float)dv[u][0], d1 = (float)dv[u][1], d2 = (float)dv[u][2], d3 = (float)dv[u][3];
+          ag[0] += d0 * ((xv[u].x - mu[u]) * rs[u]); ag[1] += d1 * ((xv[u].y - mu[u]) * rs[u]);
+          ag[2] += d2 * ((xv[u].z - mu[u]) * rs[u]); ag[3] += d3 * ((xv[u].w - mu[u]) * rs[u]);
+          ab[0] += d0; ab[1] += d1; ab[2] += d2; ab[3] += d3;
+        }
+        if (t.dy) {
+          ar[0] += (float)yb[u][0]; ar[1] += (float)yb[u][1]; ar[2] += (float)yb[u][2]; ar[3] += (float)yb[u][3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    red[0][wave][lane * 4 + j] = ag[j];
+    red[1][wave][lane * 4 + j] = ab[j];
+    red[2][wave][lane * 4 + j] = ar[j];
+  }
+  __syncthreads();
+  const int c = cg * 256 + threadIdx.x;
+  if (c < t.C) {
+    const int k = threadIdx.x;
+    if (ln) {
+      atomicAdd(t.dgamma + c, (red[0][0][k] + red[0][1][k]) + (red[0][2][k] + red[0][3][k]));
+      atomicAdd(t.dbeta + c, (red[1][0][k] + red[1][1][k]) + (red[1][2][k] + red[1][3][k]));
+    }
+    if (t.dy && t.dbias) atomicAdd(t.dbias + c, (red[2][0][k] + red[2][1][k]) + (red[2][2][k] + red[2][3][k]));
+  }
+}
+
 // out_k[c] += sum over blocks of part[b][k][c], k = 0..2; grid (ceil(3C/256), ceil(nblk/32))
 __global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ part, int nblk, int C,
                                                         float* __restrict__ o0, float* __restrict__ o1,
@@ -762,6 +831,20 @@ int launch_ln_param_grads(const bf16_t* dh, int ld16, const float* x, const floa
   else
     hipLaunchKernelGGL((ln_param_grads_kernel<bf16_t>), grid, dim3(256), 0, s, dh, ld16, x, mean, rstd,
                        (const bf16_t*)dy, ldy, dgamma, dbeta, dbias, M, C, rpb);
+  return 0;
+}
+
+int launch_col_tasks(ColTasks ts, hipStream_t s) {
+  if (ts.n < 1 || ts.n > COL_TASKS_MAX || ts.M <= 0) return -1;
+  int groups = 0;
+  for (int i = 0; i < ts.n; ++i) {
+    ColTask& t = ts.t[i];
+    if ((t.C & 3) || (t.dy && (t.ldy < t.C || (t.ldy & 3))) || (t.x && (t.ld16 < t.C || (t.ld16 & 3)))) return -1;
+    t.cg_begin = groups;
+    groups += (t.C + 255) / 256;
+  }
+  ts.rpb = 128;
+  hipLaunchKernelGGL(col_tasks_kernel, dim3(groups, (ts.M + ts.rpb - 1) / ts.rpb), dim3(256), 0, s, ts);
   return 0;
 }
 

@@ -113,9 +113,18 @@ def wgrad_layer(K, d=800, ff=3072):
     errs = [((outs_new[0] - outs_old[0]).norm() / outs_old[0].norm()).item()]
     errs += [((outs_new[i] - outs_old[i]).norm() / outs_old[i].norm()).item() for i in (1, 2, 3)]
     t_old, t_new = time_us(old), time_us(new)
-    print("wgrad layer K%5d d%d ff%d: round-1 (4 GEMMs + 4 reduces) %6.1f us %4.0f TF | grouped whole-K %6.1f us %4.0f TF"
-          " | new-vs-old rel diff %s" % (K, d, ff, t_old, flops / t_old / 1e6, t_new, flops / t_new / 1e6,
-                                         " ".join("%.1e" % e for e in errs)), flush=True)
+    line = ""
+    for cfg in [int(x) for x in os.environ.get('TN_LOOPS', '1,2,0').split(',')]:
+        lib.fact_debug_gemm_tn_cfg(cfg)
+        for o in outs_new:
+            o.zero_()
+        new()
+        torch.cuda.synchronize()
+        ref = [xin[:, :d].float().t() @ gact.float()] if False else None
+        e = ((outs_new[1] - (h2[:, :d].float().t() @ dpre.float())).norm() / outs_new[1].norm()).item()
+        line += " | loop%d %6.1f us %4.0f TF err %.1e" % (cfg, time_us(new), flops / time_us(new) / 1e6, e)
+    lib.fact_debug_gemm_tn_cfg(0)
+    print("wgrad layer K%5d: round-1 %6.1f us %4.0f TF%s" % (K, t_old, flops / t_old / 1e6, line), flush=True)
 
 
 if __name__ == "__main__":
