@@ -116,6 +116,11 @@ int fact_adam_bucket(FactHandle* h, int bucket, void* stream);
 int fact_adam_cancel(FactHandle* h);
 int fact_num_buckets(FactHandle* h, int* n);
 
+/* Gradient-bucket casts for bf16 all-reduce payloads (data-parallel path): n elements, n % 4 == 0
+ * (bucket ranges of the arenas are 64-float aligned).  Replaces nothing in the reference (TF all-reduces fp32). */
+int fact_cast_f32_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
+int fact_cast_bf16_f32(const void* src_bf16, float* dst, size_t n, void* stream);
+
 /* In-step kernel-class timing.  fact_kprof(h, 1) arms it (and clears earlier records): every instrumented launch
  * site of the following forward / backward calls is bracketed by HIP events recorded on the stream it launches
  * on, with all the stream overlap of a normal step.  fact_kprof_read synchronises the device and returns, per

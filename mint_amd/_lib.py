@@ -65,6 +65,8 @@ SIGNATURES = {
     "fact_infer_ar": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
     "fact_set_option": (_i, [_vp, C.c_char_p, _i]),
     "fact_set_grad_callback": (_i, [_vp, GRAD_CB, _vp, _vp]),
+    "fact_cast_f32_bf16": (_i, [_vp, _vp, _sz, _vp]),
+    "fact_cast_bf16_f32": (_i, [_vp, _vp, _sz, _vp]),
     "fact_op_gemm_nt": (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i,
                              _vp, _i, _vp]),
     "fact_op_gemm_tn": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),

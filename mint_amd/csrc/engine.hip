@@ -1395,6 +1395,17 @@ int fact_adam_cancel(FactHandle* h) {
   return 0;
 }
 
+int fact_cast_f32_bf16(const float* src, void* dst_bf16, size_t n, void* stream) {
+  if (!src || !dst_bf16) return fail(-1, "null argument");
+  CHK(launch_cast_bf16(src, (bf16_t*)dst_bf16, n, (hipStream_t)stream));
+  return 0;
+}
+int fact_cast_bf16_f32(const void* src_bf16, float* dst, size_t n, void* stream) {
+  if (!src_bf16 || !dst) return fail(-1, "null argument");
+  CHK(launch_cast_f32(( const bf16_t*)src_bf16, dst, n, (hipStream_t)stream));
+  return 0;
+}
+
 int fact_kprof(FactHandle* h, int on) {
   if (!h) return fail(-1, "null handle");
   h->kp.on = on != 0;

@@ -110,8 +110,9 @@ int launch_transpose_bf16(const bf16_t* src, int ld, int R, int C, bf16_t* dstT,
 // f32 rows (b, t) at src + b*batch_stride + t*F (M = B*n rows) -> bf16 [M][Fp] zero-padded
 int launch_pad_cast(const float* src, int n, size_t batch_stride, int M, int F, bf16_t* dst, int Fp,
                     hipStream_t s);
-// f32 -> bf16 flat
+// f32 -> bf16 flat, bf16 -> f32 flat (n % 4 == 0)
 int launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s);
+int launch_cast_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s);
 // out (B, na+nb, C) = concat along the sequence axis of a (B, na, C) and b (B, nb, C)
 int launch_concat_seq(const float* a, const float* b, int B, int na, int nb, int C, float* out, hipStream_t s);
 // split the cross-modal gradient (B, na+nb, C) into the two encoder gradients (f32 + bf16 copies)

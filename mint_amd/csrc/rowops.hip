@@ -686,6 +686,14 @@ __global__ void cast_bf16_kernel(const float4* __restrict__ src, bf16x4* __restr
   }
 }
 
+__global__ void cast_f32_kernel(const bf16x4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const bf16x4 v = src[i];
+    dst[i] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+}
+
 // tf.concat([a, b], axis=1): out (B, na+nb, C) from a (B, na, C) and b (B, nb, C)
 __global__ void concat_seq_kernel(const float4* __restrict__ a, const float4* __restrict__ b, int B, int na,
                                   int nb, int C4, float4* __restrict__ out) {
@@ -930,6 +938,13 @@ int launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
   if (n & 3) return -1;
   hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, s, (const float4*)src,
                      (bf16x4*)dst, n >> 2);
+  return 0;
+}
+
+int launch_cast_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s) {
+  if (n & 3) return -1;
+  hipLaunchKernelGGL(cast_f32_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, s, (const bf16x4*)src,
+                     (float4*)dst, n >> 2);
   return 0;
 }
 

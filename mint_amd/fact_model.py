@@ -270,6 +270,16 @@ class FACTModel:
         L.check(L.lib().fact_adam_begin(self._h, float(lr), float(beta_1), float(beta_2), float(epsilon)))
         self.global_step += 1
 
+    def cast_bucket_to_bf16(self, src_f32, dst_bf16, stream=None):
+        """fp32 gradient range -> bf16 communication buffer (HIP cast kernel on `stream`)."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else L.cur_stream()
+        L.check(L.lib().fact_cast_f32_bf16(L.ptr(src_f32), L.ptr(dst_bf16), src_f32.numel(), st))
+
+    def cast_bucket_from_bf16(self, src_bf16, dst_f32, stream=None):
+        """all-reduced bf16 bucket -> fp32 gradient arena range."""
+        st = C.c_void_p(stream.cuda_stream) if stream is not None else L.cur_stream()
+        L.check(L.lib().fact_cast_bf16_f32(L.ptr(src_bf16), L.ptr(dst_f32), src_bf16.numel(), st))
+
     def cancel_fused_adam(self, global_step):
         """Disarm a begin_fused_adam whose forward_backward never ran (it raised before reaching the engine)."""
         L.check(L.lib().fact_adam_cancel(self._h))

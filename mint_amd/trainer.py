@@ -90,34 +90,65 @@ def clip_local_gradients(grad_arena, clip_norm):
 
 
 class OverlappedGradReducer:
-    """Sum-all-reduces gradient buckets on a dedicated communication stream WHILE the backward pass
-    is still running: the engine reports each contiguous bucket as soon as its producers are
-    enqueued (head, cross layers L-1..0, audio stack, motion stack; ~30 MB fp32 per cross layer).
-    RCCL rings/trees run on xGMI beside the remaining dgrad/wgrad kernels; `finish()` makes the
-    compute stream wait for the collectives before the optimizer step."""
+    """Sum-all-reduces gradient buckets on a dedicated communication stream WHILE the backward pass is still
+    running: the engine reports each contiguous bucket as soon as its producers are enqueued (head, cross
+    layers L-1..0, audio stack, motion stack; ~30 MB fp32 per cross layer).  RCCL runs on xGMI beside the
+    remaining dgrad / wgrad kernels; `finish()` makes the compute stream wait for the collectives before the
+    optimizer step.
 
-    def __init__(self, model):
+    `bf16_buckets=True` halves the payload (240.8 MB instead of 481.6 MB per step): a bucket is
+    cast to bf16 into a communication buffer, all-reduced there, and written back into the fp32 arena the
+    optimizer reads (the casts are the model's `cast_bucket_*` methods: HIP kernels on the engine).  The sum
+    then carries one bf16 rounding per replica contribution.
+
+    The protocol only needs `set_grad_callback(fn, stream)`, `grad_arena` and (for bf16) the two cast methods
+    from the model, so tests/test_trainer_dist.py drives THIS class on CPU (gloo, world 2) with a stand-in
+    that reports its buckets the way the engine does."""
+
+    def __init__(self, model, bf16_buckets=False):
         self.model = model
-        self.comm = torch.cuda.Stream()
-        self.works = []
+        self.bf16 = bool(bf16_buckets)
+        self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self.works = []       # (work handle, bucket offset, count, bf16 buffer or None)
         self.fused_adam = False  # set per step by the trainer
+        self._buf16 = None
+        self.buckets_seen = []   # (bucket, offset, count) of the step in flight, in arrival order
         model.set_grad_callback(self._on_bucket, self.comm)
 
+    def _stream(self):
+        import contextlib
+        return torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()
+
     def _on_bucket(self, bucket, offset, count):
-        with torch.cuda.stream(self.comm):
-            w = dist.all_reduce(self.model.grad_arena[offset:offset + count], op=dist.ReduceOp.SUM,
-                                async_op=True)
-            if self.fused_adam:
+        self.buckets_seen.append((bucket, offset, count))
+        arena = self.model.grad_arena
+        with self._stream():
+            if self.bf16:
+                if self._buf16 is None or self._buf16.numel() != arena.numel():
+                    self._buf16 = torch.empty(arena.numel(), dtype=torch.bfloat16, device=arena.device)
+                buf = self._buf16[offset:offset + count]
+                self.model.cast_bucket_to_bf16(arena[offset:offset + count], buf, self.comm)
+                w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+            else:
+                buf = None
+                w = dist.all_reduce(arena[offset:offset + count], op=dist.ReduceOp.SUM, async_op=True)
+            if self.fused_adam and not self.bf16:
                 w.wait()  # comm stream waits for the collective, then updates this bucket
                 self.model.adam_bucket(bucket, self.comm)
             else:
-                self.works.append(w)
+                self.works.append((w, offset, count, buf))
 
     def finish(self):
-        for w in self.works:
+        arena = self.model.grad_arena
+        for w, offset, count, buf in self.works:
             w.wait()  # current (compute) stream waits for the collective
+            if buf is not None:
+                with self._stream():
+                    self.model.cast_bucket_from_bf16(buf, arena[offset:offset + count], self.comm)
         self.works = []
-        torch.cuda.current_stream().wait_stream(self.comm)
+        self.buckets_seen = []
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
 
 
 class SingleTaskTrainer:
@@ -129,7 +160,7 @@ class SingleTaskTrainer:
 
     def __init__(self, train_dataset, label_key, model, loss_fn=None, optimizer=None, metrics=None,
                  trainer_options=None, summary_fn=None, grad_clip_norm=0.0, overlap_grad_allreduce=None,
-                 fuse_optimizer=True):
+                 fuse_optimizer=True, bf16_grad_buckets=False):
         self.train_dataset = train_dataset
         self.label_key = label_key
         self.model = model
@@ -150,6 +181,7 @@ class SingleTaskTrainer:
             self.metrics = [metrics]
         self._iter = None
         self._reducer = None
+        self._bf16_buckets = bool(bf16_grad_buckets)
         if overlap_grad_allreduce is None:
             overlap_grad_allreduce = (self.num_replicas_in_sync > 1 and hasattr(model, "set_grad_callback")
                                       and dist.get_backend() == "nccl")
@@ -183,7 +215,7 @@ class SingleTaskTrainer:
         if (self._overlap or self._fuse) and hasattr(self.model, "ensure_built"):
             self.model.ensure_built(inputs)
         if self._overlap and self._reducer is None:
-            self._reducer = OverlappedGradReducer(self.model)
+            self._reducer = OverlappedGradReducer(self.model, bf16_buckets=self._bf16_buckets)
         # fused path: single replica without a gradient callback (the engine updates the buckets itself)
         fused = self._fuse and R == 1 and self._reducer is None
         step = self.optimizer.iterations  # summaries are written at the PRE-update step (:172-173)

@@ -218,6 +218,93 @@ def test_fact_v5_forward_and_grads_vs_oracle():
     assert torch.isfinite(model.grad_arena).all()
 
 
+def test_fact_v5_headline_batch_all_gradients_vs_oracle():
+    """The headline configuration at the HEADLINE batch (16 sequences = 5760 cross-modal tokens): the step runs
+    on the big-tile GEMM family (288x256 / 256x256 / 256x160 tiles, in-kernel split-K), the grouped whole-K
+    wgrad launches, the split LayerNorm backward and the LDS-resident attention kernels - exactly the kernels
+    bench.py times.  Forward, loss and ALL 184 gradient tensors (Dense kernels, biases, LayerNorm gamma / beta,
+    position tables, embeddings, head) against the fp32 CPU oracle of the same step.
+    Tolerance (bf16 MFMA operands, fp32 accumulation): forward rel-Frobenius <= 2e-2, loss rel <= 1e-2,
+    every gradient tensor cosine >= 0.99 and rel-Frobenius <= 0.1."""
+    cfg = O.FACT_V5_CFG
+    B = 16
+    model = model_builder.build(make_config(cfg), True)
+    batch = O.synthetic_batch(cfg, B, 20, seed=0, dtype=torch.float32)
+    gb = gpu_batch(batch)
+    model.build(B, 225, 35)
+    _randomize(model, seed=11)
+    params = oracle_params(model, torch.float32)
+    out = model(gb)
+    ref_loss, ref_grads, ref = O.loss_and_grads(params, cfg, batch["motion_input"], batch["audio_input"],
+                                                batch["target"])
+    assert out.shape == (B, 360, 225)
+    assert rel(out, ref) < 2e-2, rel(out, ref)
+    loss = model.forward_backward(gb, gb["target"])
+    assert abs(float(loss) - float(ref_loss)) / float(ref_loss) < 1e-2
+    names = model.variable_names
+    assert len(names) == 184
+    grads = dict(zip(names, model.gradients))
+    worst = (1.0, "")
+    for name in names:
+        c, r = cos(grads[name], ref_grads[name]), rel(grads[name], ref_grads[name])
+        worst = min(worst, (c, name))
+        assert c > 0.99, "%s cos %.5f rel %.4f" % (name, c, r)
+        assert r < 0.1, "%s rel %.4f" % (name, r)
+    print("fact_v5 B=16: worst gradient cosine %.5f (%s)" % worst)
+
+
+def test_tiny_adam_state_per_tensor_after_three_steps():
+    """Three optimizer steps on the engine vs the oracle (Keras Adam, epsilon outside the bias correction), compared
+    PER TENSOR: parameters, first and second moments.  Tolerances (bf16 gradients into fp32 Adam): m rel-Frobenius
+    <= 5e-2, v <= 1e-1 (squares double the relative gradient error), parameter UPDATE p3 - p0 cosine >= 0.98 and
+    rel-Frobenius <= 0.15 for every one of the tensors - an error confined to biases / LayerNorm would show."""
+    cfg = O.TINY_CFG
+    model = model_builder.build(make_config(cfg), True)
+    batch = O.synthetic_batch(cfg, 4, 8, seed=3)
+    gb = gpu_batch(batch)
+    model.build(4, 225, 35)
+    _randomize(model, seed=5)
+    params = oracle_params(model)
+    p0 = {k: v.clone() for k, v in params.items()}
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(vv) for k, vv in params.items()}
+    trainer = SingleTaskTrainer([gb] * 3, "target", model, optimizer=Adam(1e-3))
+    it = iter([gb] * 3)
+    for step in range(3):
+        trainer.train_step(it)
+        _, _, params, m, v = O.train_step(params, m, v, step, cfg, batch, 1e-3)
+    torch.cuda.synchronize()
+    st = model.state_dict()
+    names = model.variable_names
+    views = lambda arena: {n: arena[off:off + r * c].double() for (n, off, r, c, _k) in model._table}
+    pm, pv, pp = views(st["adam_m"]), views(st["adam_v"]), views(st["params"])
+    for n in names:
+        assert rel(pm[n], m[n].flatten()) < 5e-2, "m %s rel %.4f" % (n, rel(pm[n], m[n].flatten()))
+        assert rel(pv[n], v[n].flatten()) < 1e-1, "v %s rel %.4f" % (n, rel(pv[n], v[n].flatten()))
+        du, dr = pp[n] - p0[n].flatten(), (params[n] - p0[n]).flatten()
+        assert cos(du, dr) > 0.98, "update %s cos %.4f" % (n, cos(du, dr))
+        assert rel(du, dr) < 0.15, "update %s rel %.4f" % (n, rel(du, dr))
+
+
+def test_fact_v5_autoregressive_vs_oracle():
+    """Auto-regressive sampling at the fact_v5 dimensions (d = 800, 10 heads of 80, 2 + 2 + 12 layers, 120 / 240
+    frames): 8 generated frames, each fed back as the next motion window's last frame (fact_model.py:103-132),
+    against the fp32 CPU oracle.  Tolerance: rel-Frobenius <= 3e-2 over the rollout, <= 4e-2 on the last frame
+    (errors compound through the feedback)."""
+    cfg = O.FACT_V5_CFG
+    model = model_builder.build(make_config(cfg), False)
+    g = torch.Generator().manual_seed(13)
+    steps = 8
+    motion = torch.randn(2, 120, 225, generator=g, dtype=torch.float32)
+    audio = torch.randn(2, 240 + steps - 1, 35, generator=g, dtype=torch.float32)
+    out = model.infer_auto_regressive({"motion_input": motion.cuda(), "audio_input": audio.cuda()}, steps=steps)
+    assert out.shape == (2, steps, 225)
+    params = oracle_params(model, torch.float32)
+    ref = O.infer_auto_regressive(params, cfg, motion, audio, steps=steps)
+    assert rel(out, ref) < 3e-2, rel(out, ref)
+    assert rel(out[:, -1], ref[:, -1]) < 4e-2, rel(out[:, -1], ref[:, -1])
+
+
 def test_engine_against_reference_code_vectors():
     """HIP engine vs vectors recorded from the REFERENCE'S OWN model code (tests/golden/reference_tiny_golden.npz,
     see tests/golden/make_reference_golden.py): forward rel-Frobenius <= 2e-2, loss rel <= 1e-2, the 4-frame
@@ -323,6 +410,30 @@ def test_overlapped_allreduce_callback_path_single_rank():
             results.append((losses, torch.cat([v.flatten() for v in model.trainable_variables]).cpu()))
         assert results[0][0] == pytest.approx(results[1][0], rel=1e-5)
         assert torch.allclose(results[0][1], results[1][1], rtol=1e-4, atol=1e-6)
+        # bf16 gradient buckets (half the all-reduce payload): fp32 arena -> bf16 comm buffer (HIP cast) ->
+        # all-reduce -> back into the arena.  One replica: the only difference to the fp32 path is one bf16
+        # rounding of every gradient, i.e. rel-Frobenius ~2^-9 per tensor.
+        model = model_builder.build(make_config(cfg), True)
+        tr = SingleTaskTrainer([batch] * 3, "target", model, optimizer=Adam(1e-3), overlap_grad_allreduce=True,
+                               bf16_grad_buckets=True)
+        tr.train_step(iter([batch]))
+        ref_model = model_builder.build(make_config(cfg), True)
+        ref_model.build(4, 225, 35)
+        b2 = dict(batch)
+        tgt = b2.pop("target")
+        ref_model.forward_backward(b2, tgt)
+        g_ref = ref_model.grad_arena.clone()
+        from mint_amd.trainer import OverlappedGradReducer
+        fresh = model_builder.build(make_config(cfg), True)   # same seed -> same initial parameters as ref_model
+        fresh.build(4, 225, 35)
+        red = OverlappedGradReducer(fresh, bf16_buckets=True)
+        fresh.forward_backward(b2, tgt)
+        red.finish()
+        torch.cuda.synchronize()
+        g16 = fresh.grad_arena
+        assert torch.isfinite(g16).all()
+        assert rel(g16, g_ref) < 4e-3, rel(g16, g_ref)
+        assert torch.equal(g16, g16.to(torch.bfloat16).float()), "gradients did not pass through bf16"
     finally:
         dist.destroy_process_group()
 

@@ -493,3 +493,19 @@ def test_mse_loss_and_grad():
     d = dpred.float().view(B, n, ldp)
     _close(d[:, :, :D], pr.grad, 1e-2, 1e-6, "dpred")
     assert (d[:, :, D:] == 0).all() and (d[:, T:, :] == 0).all()
+
+
+def test_grad_bucket_casts():
+    """fp32 <-> bf16 casts of the gradient-bucket path (fact_cast_f32_bf16 / fact_cast_bf16_f32)."""
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(41)
+    n = 3 * 4096 + 64
+    x = torch.randn(n, device=DEV, generator=g) * 3.0
+    y16 = torch.empty(n, device=DEV, dtype=torch.bfloat16)
+    L.check(lib.fact_cast_f32_bf16(L.ptr(x), L.ptr(y16), n, L.cur_stream()))
+    _sync()
+    assert torch.equal(y16, x.to(torch.bfloat16))
+    z = torch.full((n,), float("nan"), device=DEV)
+    L.check(lib.fact_cast_bf16_f32(L.ptr(y16), L.ptr(z), n, L.cur_stream()))
+    _sync()
+    assert torch.equal(z, y16.float())

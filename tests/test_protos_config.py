@@ -94,3 +94,29 @@ def test_programmatic_configs_equal_text():
         assert vals(x.model[0].transformer) == vals(y.model[0].transformer)
     assert vals(a.cross_modal_model.transformer) == vals(b.cross_modal_model.transformer)
     assert pipe.train_config.learning_rate == parsed.train_config.learning_rate
+
+
+def test_shipped_reference_config_parses():
+    """The reference's own configs/fact_v5_deeper_t10_cm12.config (text proto, TrainEvalPipelineConfig) through
+    mint_amd.config_util; skipped where the reference checkout is absent (the GPU box)."""
+    import os
+    import pytest
+    path = "/root/reference/configs/fact_v5_deeper_t10_cm12.config"
+    if not os.path.exists(path):
+        pytest.skip("reference checkout not present")
+    from mint_amd import config_util
+    cfgs = config_util.get_configs_from_pipeline_file(path)
+    fm = cfgs["model"].fact_model
+    mods = {m.feature_name: m for m in fm.modality}
+    assert mods["motion"].sequence_length == 120 and mods["motion"].feature_dim == 225
+    assert mods["audio"].sequence_length == 240
+    for m in mods.values():
+        t = m.model[0].transformer
+        assert (t.hidden_size, t.num_hidden_layers, t.num_attention_heads, t.intermediate_size) == (800, 2, 10, 3072)
+    ct = fm.cross_modal_model.transformer
+    assert (ct.hidden_size, ct.num_hidden_layers, ct.num_attention_heads, ct.intermediate_size) == (800, 12, 10, 3072)
+    assert fm.cross_modal_model.output_layer.out_dim == 225
+    assert cfgs["train_config"].batch_size == 32
+    lr = cfgs["train_config"].learning_rate.manual_step_learning_rate
+    assert lr.initial_learning_rate == pytest.approx(1e-4)
+    assert [(s.step, s.learning_rate) for s in lr.schedule] == [(100000, pytest.approx(1e-5)), (150000, pytest.approx(1e-6))]
