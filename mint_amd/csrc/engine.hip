@@ -1210,6 +1210,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     h->adam_hold = value;
     return 0;
   }
+  if (!strcmp(key, "big_impl")) {  // process-wide (gemm_set_big_impl): 0 round-1 big kernel, 1 default, 2 no 256x128
+    gemm_set_big_impl(value);
+    return 0;
+  }
   if (!strcmp(key, "tn_loop")) {  // process-wide: main loop of the grouped wgrad kernel (gemm_set_tn_cfg)
     gemm_set_tn_cfg(value);
     return 0;

@@ -901,6 +901,7 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
     const bool ws = p.sk_slab && p.sk_cnt && g_splitk_max > 1 && p.splitk == 1;
     int cfg = -1, old_mr = 0;
     if (variant >= 10 && variant <= 12) cfg = variant - 10;
+    else if (variant == 14) cfg = BIG_256x128;
     else if (variant == 6) old_mr = 9;
     else if (variant == 7) old_mr = 8;
     else if (variant == 0) {
@@ -914,11 +915,17 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
       const double e9 = useful / ((double)((t9 + 255) / 256) * 256 * 288 * 256);
       const double e8 = useful / ((double)((t8 + 255) / 256) * 256 * 256 * 256);
       const int t160 = ((p.N + 159) / 160) * ((p.M + 255) / 256);
+      const int t128 = ((p.N + 127) / 128) * ((p.M + 255) / 256);
+      const bool n800 = (p.N % 160 == 0 && p.N <= 960);
       if (e9 >= 0.6 || e8 >= 0.6) {
         if (g_big_impl) cfg = (e8 > e9) ? BIG_256x256 : BIG_288x256;
         else old_mr = (e8 > e9) ? 8 : 9;
-      } else if (g_big_impl && p.N % 160 == 0 && p.N <= 960 && (t160 >= 100 || (ws && t160 >= 32))) {
-        cfg = BIG_256x160;
+      } else if (g_big_impl && n800 && p.K >= 1536 && (t160 >= 100 || (ws && t160 >= 32))) {
+        cfg = BIG_256x160;  // long K: the in-kernel split-K (with a workspace) fills the chip
+      } else if (g_big_impl == 1 && t128 >= 48 && t128 <= 512) {  // g_big_impl == 2: A/B without this config
+        // short-K N = 800 GEMMs and the wide GEMMs of a short token count (motion encoder): 256x128 tiles, two
+        // workgroups per CU (round-2 bench: N800 K800 20.1 vs 22.4 us, M1920 N3072 20.2 vs 23.1 us)
+        cfg = BIG_256x128;
       }
     }
     if (cfg == BIG_256x160 && ws) {

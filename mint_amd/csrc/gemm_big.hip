@@ -53,11 +53,12 @@ DEVINL bf16x4 tr_read(unsigned addr) {
   return r;
 }
 
-template <int WGM_, int MR_, int WGN_, int NR_>
+template <int WGM_, int MR_, int WGN_, int NR_, int NSTAGE_ = 4, int WGS_PER_CU_ = 1>
 struct BigCfg {
   static constexpr int WGM = WGM_, MR = MR_, WGN = WGN_, NR = NR_;
   static constexpr int BM = WGM * MR * 16, BN = WGN * NR * 16;
-  static constexpr int NSTAGE = 4, DIST = NSTAGE - 1;
+  static constexpr int NSTAGE = NSTAGE_, DIST = NSTAGE - 1;
+  static constexpr int WGS_PER_CU = WGS_PER_CU_;  // co-resident workgroups the register / LDS budget is sized for
   static constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16;  // 1 KiB DMA pieces per 32-deep stage
   static constexpr int A_BYTES = A_PIECES * 1024;
   static constexpr int NPIECE = A_PIECES + B_PIECES;
@@ -65,7 +66,8 @@ struct BigCfg {
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
   static constexpr int LPS_LO = NPIECE / 8, EXTRA = NPIECE % 8;  // waves < EXTRA issue one more piece
   static_assert(WGM * WGN == 8, "8 waves");
-  static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+  static_assert(NSTAGE == 3 || NSTAGE == 4, "ring depth");
+  static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS");
 };
 
 // ---- NT stage image: [rows][32 k] = 64-byte rows; logical 16-byte chunk c of row r sits at position
@@ -216,9 +218,8 @@ template <class C, bool TN, bool SWAP>
 DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1], const unsigned (&sadv)[C::LPS_LO + 1],
                          const unsigned (&voff)[C::LPS_LO + 1], const int (&dst)[C::LPS_LO + 1], int nk, int wave,
                          int wm, int wn, int lane, f32x4 (&acc)[C::MR][C::NR]) {
-  constexpr int MR = C::MR, NR = C::NR, DIST = C::DIST, STAGE = C::STAGE_BYTES;
+  constexpr int MR = C::MR, NR = C::NR, NST = C::NSTAGE, DIST = C::DIST, STAGE = C::STAGE_BYTES;
   constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
-  static_assert(C::NSTAGE == 4 && DIST == 3, "loop is unrolled over 4 ring slots");
   const int grp = wave >> 2;  // stagger group: waves 0-3 lead, waves 4-7 run one phase behind
   const bool extra = EXTRA && wave < EXTRA;
 
@@ -231,9 +232,9 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
 #pragma unroll
     for (int i = 0; i < LPS_LO + 1; ++i) sptr[i] += more ? sadv[i] : 0u;
   };
-  auto wait2 = [&]() {  // at most 2 later stages of this wave stay in flight
-    if (extra) wait_vmcnt<2 * (LPS_LO + 1)>();
-    else wait_vmcnt<2 * LPS_LO>();
+  auto wait_ahead = [&]() {  // at most DIST - 1 later stages of this wave stay in flight
+    if (extra) wait_vmcnt<(DIST - 1) * (LPS_LO + 1)>();
+    else wait_vmcnt<(DIST - 1) * LPS_LO>();
   };
 
 #pragma unroll
@@ -242,17 +243,18 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
     for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // loop-invariant fragment addresses
-  unsigned a_nt[4], b_nt[4];              // NT: per ring slot, + i * 1024 immediates
+  unsigned a_nt[NST], b_nt[NST];          // NT: per ring slot, + i * 1024 immediates
   unsigned ta[MR][2], tb[NR][2];          // TN: per unit and slot pair {0,1} / {2,3}, + immediates
   if constexpr (!TN) {
     const int r = lane & 15, chunk = lane >> 4;
     const unsigned lanepart = (unsigned)(r * 64 + ((chunk ^ ring_g(r)) << 4));
 #pragma unroll
-    for (int sl = 0; sl < 4; ++sl) {
+    for (int sl = 0; sl < NST; ++sl) {
       a_nt[sl] = (unsigned)(sl * STAGE + wm * MR * 1024) + lanepart;
       b_nt[sl] = (unsigned)(sl * STAGE + C::A_BYTES + wn * NR * 1024) + lanepart;
     }
   } else {
+    static_assert(!TN || NST == 4, "TN slot-pair addressing assumes 4 ring slots");
     const unsigned l0 = lds_addr(smem);
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
@@ -272,20 +274,21 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
 
   stage(SlotC<0>{}, 1 < nk);
   stage(SlotC<1>{}, 2 < nk);
-  stage(SlotC<2>{}, 3 < nk);
-  wait2();
+  if constexpr (DIST == 3) stage(SlotC<2>{}, 3 < nk);
+  wait_ahead();
   __builtin_amdgcn_s_barrier();  // stage 0 landed
 
-  //   phase 2k   : group 0 stages k+3 and reads k      | group 1 multiplies k-1
-  //   phase 2k+1 : group 0 multiplies k                | group 1 stages k+3 and reads k
+  //   phase 2k   : group 0 stages k+DIST and reads k   | group 1 multiplies k-1
+  //   phase 2k+1 : group 0 multiplies k                | group 1 stages k+DIST and reads k
   // Every wave retires its own pieces of stage k+1 (counted vmcnt) before the barrier that ends phase 2k+1
   // and its fragment reads (lgkmcnt) before the barrier that ends its read phase, so a ring slot is only
   // re-armed after both groups are done with it (derivation: gemm.hip gemm_nt_big_kernel).
   bf16x8 af[MR], bfr[NR];
   auto body = [&](auto slot_c, int kt) {
     constexpr int SLOT = decltype(slot_c)::value;
-    if constexpr (DMA_FIRST == 1) stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);
-    // fragment reads first, the DMA issues of stage kt+3 (another ring slot) behind them: the ~60-100 cycles
+    constexpr int NEXT = (SLOT + DIST) % NST;  // ring slot of stage kt + DIST (= the slot stage kt - 1 used)
+    if constexpr (DMA_FIRST == 1) stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
+    // fragment reads first, the DMA issues of stage kt+DIST (another ring slot) behind them: the ~60-100 cycles
     // each LDS-DMA instruction takes to issue then cover the LDS latency of the reads instead of preceding it
     if constexpr (!TN) {
 #pragma unroll
@@ -294,14 +297,14 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
       for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_nt[SLOT] + i * 1024);
       if constexpr (DMA_FIRST == 0) {
         __builtin_amdgcn_sched_barrier(0);
-        stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);
+        stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
       constexpr int SO = (SLOT & 1) * STAGE, PAIR = SLOT / 2;
       bf16x4 blo[NR], bhi[NR], alo[MR], ahi[MR];
       tn_reads<C, SO, PAIR>(ta, tb, alo, ahi, blo, bhi);
-      if constexpr (DMA_FIRST == 0) stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);
+      if constexpr (DMA_FIRST == 0) stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
       // the asm reads are invisible to hipcc's counters: retire them by hand and pin the order
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -310,7 +313,7 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
 #pragma unroll
       for (int i = 0; i < MR; ++i) af[i] = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
     }
-    if (grp == 1) wait2();
+    if (grp == 1) wait_ahead();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -319,15 +322,16 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
       for (int j = 0; j < NR; ++j)
         acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
-    if (grp == 0) wait2();
+    if (grp == 0) wait_ahead();
     __builtin_amdgcn_s_barrier();
   };
   if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one phase behind group 0
-  for (int kt = 0; kt < nk; kt += 4) {
+  for (int kt = 0; kt < nk; kt += NST) {
     body(SlotC<0>{}, kt);
     if (kt + 1 < nk) body(SlotC<1>{}, kt + 1);
     if (kt + 2 < nk) body(SlotC<2>{}, kt + 2);
-    if (kt + 3 < nk) body(SlotC<3>{}, kt + 3);
+    if constexpr (NST == 4)
+      if (kt + 3 < nk) body(SlotC<3>{}, kt + 3);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   wait_vmcnt<0>();  // the run-ahead stages past the end of K: landed before the ring is reused for staging
@@ -483,7 +487,7 @@ template <int EPI>
 DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f32x4 v);
 
 template <class C, int EPI>
-__global__ __launch_bounds__(512, 1) void big_nt_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512, 2 * C::WGS_PER_CU) void big_nt_kernel(const GemmParams p) {
   constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -942,6 +946,9 @@ using Cfg288x256 = BigCfg<2, 9, 4, 4>;
 using Cfg256x256 = BigCfg<2, 8, 4, 4>;
 using Cfg256x160 = BigCfg<4, 4, 2, 5>;
 using Cfg160x256 = BigCfg<2, 5, 4, 4>;
+// 2 workgroups per CU (3-deep ring, 72 KiB; 64x64 wave tile -> <= 128 VGPRs): the epilogue of one workgroup (bias /
+// GELU math, staging, 35-70 MB of stores for the K = 800 GEMMs) runs under the main loop of the other
+using Cfg256x128 = BigCfg<4, 4, 2, 4, 3, 2>;
 
 template <int EPI>
 int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
@@ -949,6 +956,7 @@ int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
     case BIG_288x256: return launch_big_nt_cfg<Cfg288x256, EPI>(p, s);
     case BIG_256x256: return launch_big_nt_cfg<Cfg256x256, EPI>(p, s);
     case BIG_256x160: return launch_big_nt_cfg<Cfg256x160, EPI>(p, s);
+    case BIG_256x128: return launch_big_nt_cfg<Cfg256x128, EPI>(p, s);
   }
   return -7;
 }
@@ -963,6 +971,7 @@ int big_tile_dims(int cfg, int* bm, int* bn) {
     case BIG_256x256: *bm = 256; *bn = 256; return 0;
     case BIG_256x160: *bm = 256; *bn = 160; return 0;
     case BIG_160x256: *bm = 160; *bn = 256; return 0;
+    case BIG_256x128: *bm = 256; *bn = 128; return 0;
   }
   return -1;
 }

@@ -104,8 +104,8 @@ def gemm_path(request):
     L.lib().fact_debug_force_generic_gemm(0)
 
 
-@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12],
-                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160"])
+@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14],
+                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160", "big256x128x2"])
 def nt_variant(request):
     """NT kernel choice: the engine's automatic pick, the 128x128 kernel, the round-1 big-tile kernels and
     every tile config of the big-tile family (gemm_big.hip), forced regardless of the tile-count heuristic."""
@@ -405,7 +405,7 @@ def test_attention_fwd_bwd(attn_path, B, H, n, dh):
         assert _rel_err(a, r) < 2e-2, "%s rel err %.4g" % (nm, _rel_err(a, r))
 
 
-@pytest.mark.parametrize("variant", [10, 11, 12], ids=["big288x256", "big256x256", "big256x160"])
+@pytest.mark.parametrize("variant", [10, 11, 12, 14], ids=["big288x256", "big256x256", "big256x160", "big256x128x2"])
 def test_attention_heads_epilogue_big_tiles(variant):
     """The per-head scatter epilogue (EPI_HEADS) of the big-tile family: staged through LDS, 16-byte stores,
     column -> (q/k/v, head, dim) by magic division.  Driven through the attention op (identity GEMM)."""

@@ -131,9 +131,11 @@ if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("all", "nt"):
         M = 5760
-        nt_case(M, 3072, 800, L.EPI_BIAS_GELU, [1, 6, 10, 11], "FFN1+gelu")
-        nt_case(M, 3072, 800, L.EPI_GELU_BWD, [1, 6, 10, 11], "dgrad gelu'")
-        nt_case(M, 2400, 800, L.EPI_BF16, [1, 7, 10, 11], "QKV (plain)")
+        nt_case(M, 3072, 800, L.EPI_BIAS_GELU, [1, 10, 11, 14], "FFN1+gelu")
+        nt_case(M, 3072, 800, L.EPI_GELU_BWD, [1, 10, 11, 14], "dgrad gelu'")
+        nt_case(M, 2400, 800, L.EPI_BF16, [1, 10, 11, 14], "QKV (plain)")
+        nt_case(M, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 14], "out-proj+resid")
+        nt_case(M, 800, 3072, L.EPI_BF16, [1, 112, 12, 14], "dgrad FFN1")
         nt_case(M, 800, 3072, L.EPI_F32_BIAS_RESID, [1, 112, 12], "FFN2+resid")
         nt_case(M, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 12], "out-proj+resid")
         nt_case(M, 800, 3072, L.EPI_BF16, [1, 112, 12], "dgrad FFN1")
@@ -142,8 +144,17 @@ if __name__ == "__main__":
         for Me in (3840, 1920):
             nt_case(Me, 800, 3072, L.EPI_F32_BIAS_RESID, [1, 112, 12], "enc FFN2")
             nt_case(Me, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 12], "enc out-proj")
-            nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [1, 6, 10, 11], "enc FFN1")
+            nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [1, 10, 11, 14], "enc FFN1")
         nt_case(8192, 8192, 8192, L.EPI_BF16, [1, 7, 11], "8192^3")
+    if what == "small":
+        for Me in (5760, 3840, 1920):
+            nt_case(Me, 800, 800, L.EPI_BF16, [1, 112, 14], "N800 K800 bf16")
+            nt_case(Me, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 14], "N800 K800 resid")
+        for Me in (3840, 1920):
+            nt_case(Me, 2400, 800, L.EPI_BF16, [1, 10, 11, 14], "enc QKV")
+            nt_case(Me, 3072, 800, L.EPI_GELU_BWD, [1, 10, 11, 14], "enc gelu'")
+            nt_case(Me, 800, 3072, L.EPI_BF16, [1, 12, 14], "enc dFFN1")
+            nt_case(Me, 800, 2400, L.EPI_BF16, [1, 12, 14], "enc dQKV")
     if what == "pmc":  # few launches of the kernels of interest (for rocprofv3 --pmc passes)
         ITERS = 4
         globals()["ITERS"] = 4
