@@ -1,0 +1,74 @@
+"""Per-kernel PMC table over whole train steps: merge the rocpd databases of several `rocprofv3 --kernel-trace
+--pmc <set> -- python bench.py ...` passes (one directory per pass) into one table.
+
+  python tools/step_pmc.py OUT.txt DIR_PASS1 DIR_PASS2 [...]
+
+Counter collection serialises the dispatches, so cycles (GRBM_GUI_ACTIVE / 8 XCDs) is each kernel's stand-alone
+duration in shader clocks, not its contention-stretched in-step duration.  HBM bytes follow
+MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate passes, and the
+gfx950 FETCH_SIZE is doubled for wide coalesced streams."""
+import collections
+import glob
+import sqlite3
+import sys
+
+
+def load(d, agg, calls):
+    for db in glob.glob(d + "/**/*.db", recursive=True):
+        c = sqlite3.connect(db)
+        try:
+            cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+        except Exception:
+            continue
+        if "kernel_name" not in cols:
+            continue
+        ki, ni, vi = cols.index("kernel_name"), cols.index("counter_name"), cols.index("value")
+        seen = collections.defaultdict(lambda: collections.defaultdict(int))
+        for r in c.execute("select * from counters_collection"):
+            agg[r[ki]][r[ni]][0] += r[vi]
+            agg[r[ki]][r[ni]][1] += 1
+            seen[r[ki]][r[ni]] += 1
+        for k, cs in seen.items():
+            calls[k] = max(calls[k], max(cs.values()))
+
+
+def main():
+    out = sys.argv[1]
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
+    calls = collections.defaultdict(int)
+    for d in sys.argv[2:]:
+        load(d, agg, calls)
+
+    def mean(k, n):
+        s, c = agg[k].get(n, (0.0, 0))
+        return s / c if c else None
+
+    rows = []
+    for k in agg:
+        gui = mean(k, "GRBM_GUI_ACTIVE")
+        cyc = gui / 8.0 if gui else None
+        busy, wave = mean(k, "SQ_VALU_MFMA_BUSY_CYCLES"), mean(k, "SQ_WAVE_CYCLES")
+        wait, conf = mean(k, "SQ_WAIT_INST_ANY"), mean(k, "SQ_LDS_BANK_CONFLICT")
+        fetch, write = mean(k, "FETCH_SIZE"), mean(k, "WRITE_SIZE")
+        rows.append(dict(
+            name=k, calls=calls[k], cycles=cyc,
+            mfma=(100.0 * busy / (1024.0 * cyc)) if busy is not None and cyc else None,
+            conflict=(100.0 * conf / wave) if conf is not None and wave else None,
+            wait=(100.0 * wait / wave) if wait is not None and wave else None,
+            rd_mb=(2.0 * fetch * 1024 / 1e6) if fetch is not None else None,
+            wr_mb=(write * 1024 / 1e6) if write is not None else None))
+    rows.sort(key=lambda r: -((r["cycles"] or 0) * r["calls"]))
+    f = lambda v, w, p: ("%*.*f" % (w, p, v)) if v is not None else " " * (w - 1) + "-"
+    lines = ["%-66s %6s %10s %7s %9s %7s %9s %9s" % ("kernel", "calls", "cycles", "mfma%", "conflict%", "wait%",
+                                                   "read_MB", "write_MB")]
+    for r in rows[:48]:
+        lines.append("%-66s %6d %s %s %s %s %s %s" % (r["name"][:66], r["calls"], f(r["cycles"], 10, 0),
+                                                     f(r["mfma"], 7, 1), f(r["conflict"], 9, 2), f(r["wait"], 7, 1),
+                                                     f(r["rd_mb"], 9, 1), f(r["wr_mb"], 9, 1)))
+    text = "\n".join(lines)
+    print(text)
+    open(out, "a").write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()
