@@ -829,6 +829,601 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_res_kernel(const AttnParams
   }
 }
 
+// =============================================================================================
+// Streaming family (round 2).  The LDS-resident kernels above put one 8..12-wave workgroup per (batch, head)
+// on a CU: 160 workgroups for 256 CUs, and each of them first waits ~12k cycles for its 138 KiB of K/V (or
+// Q/dO) before any MFMA issues (PMC round 2: 9-14 % MFMA busy).  Here a workgroup is 4 waves x 32 own rows
+// (queries for forward / dQ, keys for dK/dV) = a 128-row block of one head, grid = (ceil(n/128), B*H) = 480
+// workgroups at FACT's cross-modal shape, and the OTHER side of the product is streamed through a 4-slot LDS
+// ring in 32-row stages (two swizzled [32][DHP] images = the img96 layout above, 12 KiB) by 16-byte LDS-DMA with
+// counted vmcnt: 48 KiB per workgroup, so 2-3 workgroups share a CU and one's DMA / softmax / epilogue runs
+// under another's MFMAs.  One raw s_barrier per stage:
+//   top of step t : wait for this wave's pieces of stage t (two later stages stay in flight), barrier,
+//                   issue stage t+3 into the slot stage t-1 used (everyone's reads of it precede the barrier)
+// Fragment conventions are those of the resident kernels.  Transpose reads are inline asm (hipcc puts a full
+// vmcnt(0) in front of its ds_read_tr builtin while an LDS-DMA is in flight), retired by a hand lgkmcnt(0).
+// =============================================================================================
+template <int DH>
+struct SG {
+  static constexpr int DHP = Geo<DH>::DHP, ROWB = DHP * 2, CPR = DHP / 8;
+  static constexpr int IMG = 32 * ROWB;    // one [32][DHP] image
+  static constexpr int PPI = IMG / 1024;   // DMA pieces per image
+  static constexpr int PPW = 2 * PPI / 4;  // pieces per wave per stage (2 images, 4 waves)
+  static constexpr int NSLOT = 4;
+};
+template <int S>
+struct SlotK { static constexpr int value = S; };
+
+template <int N>
+DEVINL void st_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+DEVINL void st_wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int OFF>
+DEVINL bf16x4 st_tr(unsigned addr) {
+  static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+  bf16x4 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+DEVINL unsigned st_lds_addr(const unsigned char* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)p;
+}
+
+// per-wave DMA plan of a stage: this wave's PPW pieces of the two images
+template <int DH>
+struct StDma {
+  const bf16_t* src[SG<DH>::PPW];  // per-lane source of tile 0 (swizzle applied to the source chunk)
+  int dst[SG<DH>::PPW];            // byte offset of the piece inside a stage
+};
+template <int DH>
+DEVINL void st_dma_init(StDma<DH>& d, const bf16_t* img0, const bf16_t* img1, int wave, int lane) {
+  using S = SG<DH>;
+#pragma unroll
+  for (int i = 0; i < S::PPW; ++i) {
+    const int P = wave * S::PPW + i, im = P / S::PPI, pi = P - im * S::PPI;
+    const int q = pi * 64 + lane, r = q / S::CPR, cp = q - r * S::CPR;
+    const int c = cp ^ res_g(r);
+    d.src[i] = (im ? img1 : img0) + (size_t)r * S::DHP + c * 8;
+    d.dst[i] = im * S::IMG + pi * 1024;
+  }
+}
+template <int DH>
+DEVINL void st_dma_issue(const StDma<DH>& d, unsigned char* stage, int tile) {
+  using S = SG<DH>;
+#pragma unroll
+  for (int i = 0; i < S::PPW; ++i)
+    __builtin_amdgcn_global_load_lds((gbl_cvoid*)(d.src[i] + (size_t)tile * 32 * S::DHP), (lds_void*)(stage + d.dst[i]),
+                                     16, 0, 0);
+}
+
+// row fragment (contraction over the head dim) of tile-local rows sub*16.. of an image
+template <int DH>
+DEVINL bf16x8 st_frag_row(const unsigned char* img, int sub, int kd, int lane) {
+  return res_frag_row<SG<DH>::DHP>(img, sub * 16, kd, lane);
+}
+// per-lane LDS byte addresses (image base 0) for the token-contracting fragments: even / odd 16-dim tiles
+struct StTrAddr { unsigned e, o; };
+template <int DH>
+DEVINL StTrAddr st_tr_addr(unsigned lds0, int lane) {
+  const int g = lane >> 4, s = lane & 15;
+  const int r = g * 4 + (s >> 2), low = ((s & 3) >> 1) ^ res_g(r);
+  StTrAddr a;
+  a.e = lds0 + (unsigned)(r * SG<DH>::ROWB + low * 16 + (s & 1) * 8);
+  a.o = lds0 + (unsigned)(r * SG<DH>::ROWB + (low ^ 2) * 16 + (s & 1) * 8);
+  return a;
+}
+// all ND token-contracting fragments [16 dims of tile dt][32 tokens] of the image at byte offset OFF (compile time)
+template <int DH, int OFF, int DT>
+DEVINL void st_tr_all(const StTrAddr& a, bf16x4 (&lo)[Geo<DH>::ND], bf16x4 (&hi)[Geo<DH>::ND]) {
+  if constexpr (DT < Geo<DH>::ND) {
+    constexpr int O = OFF + (DT >> 1) * 64;
+    lo[DT] = st_tr<O>((DT & 1) ? a.o : a.e);
+    hi[DT] = st_tr<O + 16 * SG<DH>::ROWB>((DT & 1) ? a.o : a.e);
+    st_tr_all<DH, OFF, DT + 1>(a, lo, hi);
+  }
+}
+// the asm reads are invisible to hipcc's counters: retire them and tie the fragments to the wait
+template <int N>
+DEVINL void st_tr_retire(bf16x4 (&lo)[N], bf16x4 (&hi)[N]) {
+  st_wait_lgkm0();
+#pragma unroll
+  for (int i = 0; i < N; ++i) asm volatile("" : "+v"(lo[i]), "+v"(hi[i]));
+}
+
+DEVINL float st_max_f32(float a, float b) {  // single v_max_f32 (fmaxf adds canonicalising v_max on MFMA outputs)
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max over the 4 lanes {l, l^16, l^32, l^48} with the gfx950 row / half swaps (no LDS round trip)
+DEVINL float st_allmax4(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  const float a = st_max_f32(__builtin_bit_cast(float, r0), __builtin_bit_cast(float, r1));
+  const unsigned ua = __builtin_bit_cast(unsigned, a);
+  const auto q = __builtin_amdgcn_permlane32_swap(ua, ua, false, false);
+  const unsigned q0 = q[0], q1 = q[1];
+  return st_max_f32(__builtin_bit_cast(float, q0), __builtin_bit_cast(float, q1));
+}
+DEVINL float st_allsum4(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  const float a = __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+  const unsigned ua = __builtin_bit_cast(unsigned, a);
+  const auto q = __builtin_amdgcn_permlane32_swap(ua, ua, false, false);
+  const unsigned q0 = q[0], q1 = q[1];
+  return __builtin_bit_cast(float, q0) + __builtin_bit_cast(float, q1);
+}
+
+constexpr float ST_THR = 6.0f;  // lazy running max: P = exp2(t) stays below 2^6 between exact updates
+
+// ---- forward -------------------------------------------------------------------------------------
+// Lean softmax: the running row maximum m is only raised when a score exceeds it by more than ST_THR (log2
+// units; wave-uniform test, no cross-lane traffic on the common path) - softmax is shift invariant, so any m
+// that keeps exp2 in range is exact up to rounding - and the row sum is not a VALU reduction: a constant
+// "ones" A-fragment adds one 16-row tile to O^T whose row 0 is sum_k P[k][q], accumulated (and rescaled) by the
+// MFMA pipe from the same bf16 P that multiplies V.
+template <int DH>
+__global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p) {
+  using G = Geo<DH>;
+  using S = SG<DH>;
+  constexpr int IMG = S::IMG, STAGE = 2 * IMG, PPW = S::PPW, ND = G::ND;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y;
+  const int T = (p.n + 31) >> 5;
+  const size_t row_base = (size_t)bh * p.NP * G::DHP;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = q0 < p.n;  // wave-uniform; inactive waves still stage and synchronise
+  if (p.dbg & 512) return;
+
+  bf16x8 Qf[2][G::KD];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int kd = 0; kd < G::KD; ++kd) {
+      Qf[qs][kd] = zero_bf16x8();
+      if (!(p.dbg & 256))
+      Qf[qs][kd] = *reinterpret_cast<const bf16x8*>(
+          p.qrow + row_base + (size_t)(q0 + qs * 16 + (lane & 15)) * G::DHP + kd * 32 + g * 8);
+    }
+  StDma<DH> dma;
+  st_dma_init<DH>(dma, p.krow + row_base, p.vrow + row_base, wave, lane);
+  st_dma_issue<DH>(dma, smem, 0);
+  st_dma_issue<DH>(dma, smem + STAGE, min(1, T - 1));
+  st_dma_issue<DH>(dma, smem + 2 * STAGE, min(2, T - 1));
+
+  // the compiler must see the Q loads retired BEFORE the loop (otherwise it drains vmcnt to 0 in every step)
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int kd = 0; kd < G::KD; ++kd) asm volatile("" : "+v"(Qf[qs][kd]));
+  const StTrAddr va = st_tr_addr<DH>(st_lds_addr(smem), lane);
+  f32x4 O[2][ND + 1];  // [ND]: the ones tile (row sums)
+  float m[2] = {0.f, 0.f};
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int dt = 0; dt <= ND; ++dt) O[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones = zero_bf16x8();
+  if ((lane & 15) == 0) {
+    const bf16_t one = (bf16_t)1.0f;
+    ones = bf16x8{one, one, one, one, one, one, one, one};
+  }
+  const float sc = p.scale * LOG2E;
+  const int dbg = p.dbg;
+
+  auto body = [&](auto slot_c, int kt) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    st_wait_vm<2 * PPW>();
+    if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
+    if (!(dbg & 1)) st_dma_issue<DH>(dma, smem + ((SLOT + 3) & 3) * STAGE, min(kt + 3, T - 1));
+    if (!active) return;
+    const unsigned char* Kimg = smem + SLOT * STAGE;
+    f32x4 s[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!(dbg & 4)) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kd = 0; kd < G::KD; ++kd) {
+        const bf16x8 kf = st_frag_row<DH>(Kimg, ks, kd, lane);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = mfma16(kf, Qf[qs][kd], s[ks][qs]);
+      }
+    }
+    // V^T fragments of this stage: issued now, consumed after the softmax
+    bf16x4 vlo[ND], vhi[ND];
+    if (!(dbg & 64)) st_tr_all<DH, SLOT * STAGE + IMG, 0>(va, vlo, vhi);
+    else {
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) { vlo[dt] = bf16x4{}; vhi[dt] = bf16x4{}; }
+    }
+    if (kt == T - 1 && (p.n & 31)) {  // padded keys only exist in the last tile (wave-uniform)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool valid = (kt * 32 + ks * 16 + g * 4 + r) < p.n;
+#pragma unroll
+          for (int qs = 0; qs < 2; ++qs) s[ks][qs][r] = valid ? s[ks][qs][r] : -INFINITY;
+        }
+    }
+    float t[2][8], mx[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        t[qs][r] = fmaf(s[0][qs][r], sc, -m[qs]);
+        t[qs][4 + r] = fmaf(s[1][qs][r], sc, -m[qs]);
+      }
+      mx[qs] = st_max_f32(st_max_f32(st_max_f32(t[qs][0], t[qs][1]), st_max_f32(t[qs][2], t[qs][3])),
+                          st_max_f32(st_max_f32(t[qs][4], t[qs][5]), st_max_f32(t[qs][6], t[qs][7])));
+    }
+    if (kt == 0 || __any(st_max_f32(mx[0], mx[1]) > ST_THR)) {
+      // exact update of the running maximum (always on the first tile, then only when a score outgrew it)
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        const float tm = st_allmax4(mx[qs]);                  // row maximum of this tile relative to m
+        const float d = (kt == 0) ? tm : fmaxf(tm, 0.f);      // raise only
+        m[qs] += d;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[qs][j] -= d;
+        if (kt != 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+          for (int dt = 0; dt <= ND; ++dt) {
+            O[qs][dt][0] *= alpha; O[qs][dt][1] *= alpha; O[qs][dt][2] *= alpha; O[qs][dt][3] *= alpha;
+          }
+        }
+      }
+    }
+    bf16x8 pb[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      f32x4 p0, p1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p0[r] = (dbg & 2) ? t[qs][r] : __builtin_amdgcn_exp2f(t[qs][r]);
+        p1[r] = (dbg & 2) ? t[qs][4 + r] : __builtin_amdgcn_exp2f(t[qs][4 + r]);
+      }
+      pb[qs] = pack8(p0, p1);
+    }
+    st_tr_retire<ND>(vlo, vhi);
+    if (dbg & 8) {
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) O[qs][0][0] += (float)pb[qs][0] + (float)vlo[0][0];
+      return;
+    }
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      const bf16x8 vf = cat4(vlo[dt], vhi[dt]);
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) O[qs][dt] = mfma16(vf, pb[qs], O[qs][dt]);
+    }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) O[qs][ND] = mfma16(ones, pb[qs], O[qs][ND]);
+  };
+  if (!(p.dbg & 1024))
+  for (int kt = 0; kt < T; kt += 4) {
+    body(SlotK<0>{}, kt);
+    if (kt + 1 < T) body(SlotK<1>{}, kt + 1);
+    if (kt + 2 < T) body(SlotK<2>{}, kt + 2);
+    if (kt + 3 < T) body(SlotK<3>{}, kt + 3);
+  }
+  st_wait_vm<0>();  // run-ahead stages: landed before the LDS is handed to the next workgroup
+  if (!active) return;
+  const int b = bh / p.H, h = bh - b * p.H;
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    // row sum: row 0 of the ones tile = element 0 of lane group 0; hand it to the query's other 3 lanes
+    const float lt = __shfl(O[qs][ND][0], lane & 15, 64);
+    const float inv = 1.0f / lt;
+    const int t = q0 + qs * 16 + (lane & 15);
+    if (g == 0 && t < p.NP) p.lse2[(size_t)bh * p.NP + t] = m[qs] + __log2f(lt);
+    if (t < p.n && (!(p.dbg & 128) || lt == 12345.f)) {
+      bf16_t* orow = p.out + ((size_t)b * p.n + t) * p.ldo + h * DH + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        bf16x4 o = {(bf16_t)(O[qs][dt][0] * inv), (bf16_t)(O[qs][dt][1] * inv),
+                    (bf16_t)(O[qs][dt][2] * inv), (bf16_t)(O[qs][dt][3] * inv)};
+        *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
+      }
+    }
+  }
+}
+
+// ---- dQ ------------------------------------------------------------------------------------------
+template <int DH>
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_st_kernel(const AttnParams p) {
+  using G = Geo<DH>;
+  using S = SG<DH>;
+  constexpr int IMG = S::IMG, STAGE = 2 * IMG, PPW = S::PPW, ND = G::ND;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y;
+  const int T = (p.n + 31) >> 5;
+  const size_t row_base = (size_t)bh * p.NP * G::DHP;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const bool active = q0 < p.n;
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  bf16x8 Qf[2][G::KD], dOf[2][G::KD];
+  float L2q[2], Dq[2];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    const int q = q0 + qs * 16 + (lane & 15);
+    float part = 0.f;  // D[q] = rowsum(dO o O): this lane's 8 head columns per 32-column slab
+#pragma unroll
+    for (int kd = 0; kd < G::KD; ++kd) {
+      const size_t off = row_base + (size_t)q * G::DHP + kd * 32 + g * 8;
+      Qf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.qrow + off);
+      dOf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.dorow + off);
+      const int d0 = kd * 32 + g * 8;
+      if (q < p.n && d0 < DH) {
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(p.o + ((size_t)b * p.n + q) * p.ldo + h * DH + d0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += (float)dOf[qs][kd][j] * (float)ov[j];
+      }
+    }
+    part = st_allsum4(part);
+    L2q[qs] = p.lse2[(size_t)bh * p.NP + q];
+    Dq[qs] = part;
+    if (g == 0) p.dsum[(size_t)bh * p.NP + q] = part;  // for the dK/dV kernel (0 on padded query rows)
+  }
+  StDma<DH> dma;
+  st_dma_init<DH>(dma, p.krow + row_base, p.vrow + row_base, wave, lane);
+  st_wait_vm<0>();  // the operand loads above: the counted waits below then only see DMA pieces
+  st_dma_issue<DH>(dma, smem, 0);
+  st_dma_issue<DH>(dma, smem + STAGE, min(1, T - 1));
+  st_dma_issue<DH>(dma, smem + 2 * STAGE, min(2, T - 1));
+  const StTrAddr ka = st_tr_addr<DH>(st_lds_addr(smem), lane);
+  f32x4 dQ[2][ND];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) dQ[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float sc = p.scale * LOG2E;
+
+  auto body = [&](auto slot_c, int kt) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    st_wait_vm<2 * PPW>();
+    __builtin_amdgcn_s_barrier();
+    st_dma_issue<DH>(dma, smem + ((SLOT + 3) & 3) * STAGE, min(kt + 3, T - 1));
+    if (!active) return;
+    const unsigned char* Kimg = smem + SLOT * STAGE;
+    const unsigned char* Vimg = Kimg + IMG;
+    f32x4 s[2][2], dp[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kd = 0; kd < G::KD; ++kd) {
+        const bf16x8 kf = st_frag_row<DH>(Kimg, ks, kd, lane);
+        const bf16x8 vf = st_frag_row<DH>(Vimg, ks, kd, lane);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+          s[ks][qs] = mfma16(kf, Qf[qs][kd], s[ks][qs]);
+          dp[ks][qs] = mfma16(vf, dOf[qs][kd], dp[ks][qs]);
+        }
+      }
+    const bool last = (kt == T - 1) && (p.n & 31);
+    bf16x8 dsb[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      f32x4 d0, d1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p0 = __builtin_amdgcn_exp2f(fmaf(s[0][qs][r], sc, -L2q[qs]));
+        float p1 = __builtin_amdgcn_exp2f(fmaf(s[1][qs][r], sc, -L2q[qs]));
+        if (last) {
+          if ((kt * 32 + g * 4 + r) >= p.n) p0 = 0.f;
+          if ((kt * 32 + 16 + g * 4 + r) >= p.n) p1 = 0.f;
+        }
+        d0[r] = p0 * (dp[0][qs][r] - Dq[qs]);
+        d1[r] = p1 * (dp[1][qs][r] - Dq[qs]);
+      }
+      dsb[qs] = pack8(d0, d1);
+    }
+    bf16x4 klo[ND], khi[ND];  // (after the math: 20 registers less across it; the other waves of the SIMD cover the latency)
+    st_tr_all<DH, SLOT * STAGE, 0>(ka, klo, khi);
+    st_tr_retire<ND>(klo, khi);
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      const bf16x8 ktf = cat4(klo[dt], khi[dt]);
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) dQ[qs][dt] = mfma16(ktf, dsb[qs], dQ[qs][dt]);
+    }
+  };
+  for (int kt = 0; kt < T; kt += 4) {
+    body(SlotK<0>{}, kt);
+    if (kt + 1 < T) body(SlotK<1>{}, kt + 1);
+    if (kt + 2 < T) body(SlotK<2>{}, kt + 2);
+    if (kt + 3 < T) body(SlotK<3>{}, kt + 3);
+  }
+  st_wait_vm<0>();
+  if (!active) return;
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    const int t = q0 + qs * 16 + (lane & 15);
+    if (t < p.n) {
+      bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * p.ldq + h * DH + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        bf16x4 o = {(bf16_t)(dQ[qs][dt][0] * p.scale), (bf16_t)(dQ[qs][dt][1] * p.scale),
+                    (bf16_t)(dQ[qs][dt][2] * p.scale), (bf16_t)(dQ[qs][dt][3] * p.scale)};
+        *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
+      }
+    }
+  }
+}
+
+// ---- dK / dV -------------------------------------------------------------------------------------
+// Own rows = 32 keys per wave (K, V fragments and both accumulators in registers); streamed: Q and dO tiles
+// plus the 32 log-sum-exp / rowsum(dO o O) values of the tile's queries (one 256-byte piece, wave 0).
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_st_kernel(const AttnParams p) {
+  using G = Geo<DH>;
+  using S = SG<DH>;
+  constexpr int IMG = S::IMG, STAGE = 2 * IMG + 256, PPW = S::PPW, ND = G::ND;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y;
+  const int T = (p.n + 31) >> 5;
+  const size_t row_base = (size_t)bh * p.NP * G::DHP;
+  const int key0 = blockIdx.x * 128 + wave * 32;
+  const bool active = key0 < p.n;
+  const int b = bh / p.H, h = bh - b * p.H;
+
+  bf16x8 Kf[2][G::KD], Vf[2][G::KD];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int kd = 0; kd < G::KD; ++kd) {
+      const size_t off = row_base + (size_t)(key0 + ks * 16 + (lane & 15)) * G::DHP + kd * 32 + g * 8;
+      Kf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.krow + off);
+      Vf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.vrow + off);
+    }
+  StDma<DH> dma;
+  st_dma_init<DH>(dma, p.qrow + row_base, p.dorow + row_base, wave, lane);
+  // the statistics piece: lanes 0-7 fetch 4 lse2 values each, lanes 8-15 4 dsum values each
+  const float* stat_src = (lane < 8 ? p.lse2 : p.dsum) + (size_t)bh * p.NP + (lane & 7) * 4;
+  auto issue = [&](int slot, int tile) {
+    st_dma_issue<DH>(dma, smem + slot * STAGE, tile);
+    if (wave == 0 && lane < 16)
+      __builtin_amdgcn_global_load_lds((gbl_cvoid*)(stat_src + tile * 32), (lds_void*)(smem + slot * STAGE + 2 * IMG), 16,
+                                       0, 0);
+  };
+  st_wait_vm<0>();
+  issue(0, 0);
+  issue(1, min(1, T - 1));
+  issue(2, min(2, T - 1));
+  const StTrAddr ta = st_tr_addr<DH>(st_lds_addr(smem), lane);
+  f32x4 dK[2][ND], dV[2][ND];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      dK[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dV[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  bool kvalid[2];
+  kvalid[0] = (key0 + (lane & 15)) < p.n;
+  kvalid[1] = (key0 + 16 + (lane & 15)) < p.n;
+  const float sc = p.scale * LOG2E;
+
+  auto body = [&](auto slot_c, int qt) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    if (wave == 0) st_wait_vm<2 * (PPW + 1)>();
+    else st_wait_vm<2 * PPW>();
+    __builtin_amdgcn_s_barrier();
+    issue((SLOT + 3) & 3, min(qt + 3, T - 1));
+    if (!active) return;
+    const unsigned char* Qimg = smem + SLOT * STAGE;
+    const unsigned char* dOimg = Qimg + IMG;
+    const float* st = reinterpret_cast<const float*>(Qimg + 2 * IMG);
+    f32x4 s[2][2], dp[2][2];  // [qsub][ksub]
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        s[qs][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[qs][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+      for (int kd = 0; kd < G::KD; ++kd) {
+        const bf16x8 qf = st_frag_row<DH>(Qimg, qs, kd, lane);
+        const bf16x8 df = st_frag_row<DH>(dOimg, qs, kd, lane);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s[qs][ks] = mfma16(qf, Kf[ks][kd], s[qs][ks]);
+          dp[qs][ks] = mfma16(df, Vf[ks][kd], dp[qs][ks]);
+        }
+      }
+    const f32x4 l2a = *reinterpret_cast<const f32x4*>(st + g * 4);
+    const f32x4 l2b = *reinterpret_cast<const f32x4*>(st + 16 + g * 4);
+    const f32x4 dda = *reinterpret_cast<const f32x4*>(st + 32 + g * 4);
+    const f32x4 ddb = *reinterpret_cast<const f32x4*>(st + 48 + g * 4);
+    const bool lastq = (qt == T - 1) && (p.n & 31);
+    bf16x8 pb[2], dsb[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 p0, p1, d0, d1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // padded keys AND padded query rows are masked (shared dO scratch: see the tiled kernel)
+        bool ok0 = kvalid[ks], ok1 = kvalid[ks];
+        if (lastq) {
+          ok0 = ok0 && (qt * 32 + g * 4 + r) < p.n;
+          ok1 = ok1 && (qt * 32 + 16 + g * 4 + r) < p.n;
+        }
+        p0[r] = ok0 ? __builtin_amdgcn_exp2f(fmaf(s[0][ks][r], sc, -l2a[r])) : 0.f;
+        p1[r] = ok1 ? __builtin_amdgcn_exp2f(fmaf(s[1][ks][r], sc, -l2b[r])) : 0.f;
+        d0[r] = p0[r] * (dp[0][ks][r] - dda[r]);
+        d1[r] = p1[r] * (dp[1][ks][r] - ddb[r]);
+      }
+      pb[ks] = pack8(p0, p1);
+      dsb[ks] = pack8(d0, d1);
+    }
+    bf16x4 qlo[ND], qhi[ND], olo[ND], ohi[ND];
+    st_tr_all<DH, SLOT * STAGE + IMG, 0>(ta, olo, ohi);
+    st_tr_all<DH, SLOT * STAGE, 0>(ta, qlo, qhi);
+    st_tr_retire<ND>(olo, ohi);
+    st_tr_retire<ND>(qlo, qhi);
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt) {
+      const bf16x8 dof = cat4(olo[dt], ohi[dt]);
+      const bf16x8 qtf = cat4(qlo[dt], qhi[dt]);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        dV[ks][dt] = mfma16(dof, pb[ks], dV[ks][dt]);
+        dK[ks][dt] = mfma16(qtf, dsb[ks], dK[ks][dt]);
+      }
+    }
+  };
+  for (int qt = 0; qt < T; qt += 4) {
+    body(SlotK<0>{}, qt);
+    if (qt + 1 < T) body(SlotK<1>{}, qt + 1);
+    if (qt + 2 < T) body(SlotK<2>{}, qt + 2);
+    if (qt + 3 < T) body(SlotK<3>{}, qt + 3);
+  }
+  st_wait_vm<0>();
+  if (!active) return;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int t = key0 + ks * 16 + (lane & 15);
+    if (t < p.n) {
+      bf16_t* krow_o = p.dqkv + ((size_t)b * p.n + t) * p.ldq + p.hid + h * DH + g * 4;
+      bf16_t* vrow_o = krow_o + p.hid;
+#pragma unroll
+      for (int dt = 0; dt < ND; ++dt) {
+        bf16x4 ok = {(bf16_t)(dK[ks][dt][0] * p.scale), (bf16_t)(dK[ks][dt][1] * p.scale),
+                     (bf16_t)(dK[ks][dt][2] * p.scale), (bf16_t)(dK[ks][dt][3] * p.scale)};
+        bf16x4 ov = {(bf16_t)dV[ks][dt][0], (bf16_t)dV[ks][dt][1], (bf16_t)dV[ks][dt][2],
+                     (bf16_t)dV[ks][dt][3]};
+        *reinterpret_cast<bf16x4*>(krow_o + dt * 16) = ok;
+        *reinterpret_cast<bf16x4*>(vrow_o + dt * 16) = ov;
+      }
+    }
+  }
+}
+
+int g_attn_variant = 0;  // 0 = streaming family (default), 1 = round-1 dispatch (LDS-resident when it fits, else tiled)
 int g_attn_force_tiled = 0;  // test knob: 1 = always use the tiled (streaming) kernels
 
 // LDS bytes of the resident kernels for n tokens; 0 = does not fit -> tiled kernels
@@ -865,8 +1460,26 @@ int allow_big_lds(K kernel, bool* done) {
   return 0;
 }
 
+template <typename K>
+int allow_lds_bytes(K kernel, bool* done, size_t bytes) {
+  if (!*done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+      return -20;
+    *done = true;
+  }
+  return 0;
+}
+
 template <int DH>
 int fwd_t(const AttnParams& p, hipStream_t s) {
+  if (g_attn_variant == 0 && !g_attn_force_tiled) {
+    constexpr size_t lds = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG;
+    static bool attr = false;
+    if (int rc = allow_lds_bytes(attn_fwd_st_kernel<DH>, &attr, lds)) return rc;
+    hipLaunchKernelGGL(attn_fwd_st_kernel<DH>, dim3((p.n + 127) / 128, p.B * p.H), dim3(256), lds, s, p);
+    return 0;
+  }
   const size_t lds = res_lds_bytes<DH>(p.n, 0);
   if (lds) {
     static bool attr = false;
@@ -881,6 +1494,16 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
 }
 template <int DH>
 int bwd_t(const AttnParams& p, hipStream_t s) {
+  if (g_attn_variant == 0 && !g_attn_force_tiled) {
+    constexpr size_t lds1 = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG, lds2 = (size_t)SG<DH>::NSLOT * (2 * SG<DH>::IMG + 256);
+    static bool attr1 = false, attr2 = false;
+    if (int rc = allow_lds_bytes(attn_bwd_dq_st_kernel<DH>, &attr1, lds1)) return rc;
+    if (int rc = allow_lds_bytes(attn_bwd_dkdv_st_kernel<DH>, &attr2, lds2)) return rc;
+    const dim3 grid((p.n + 127) / 128, p.B * p.H);
+    hipLaunchKernelGGL(attn_bwd_dq_st_kernel<DH>, grid, dim3(256), lds1, s, p);
+    hipLaunchKernelGGL(attn_bwd_dkdv_st_kernel<DH>, grid, dim3(256), lds2, s, p);
+    return 0;
+  }
   const int total = p.B * p.H * p.NP;
   const size_t lds1 = res_lds_bytes<DH>(p.n, 1), lds2 = res_lds_bytes<DH>(p.n, 2);
   // the LDS-resident dQ kernel computes D = rowsum(dO o O) itself; only the tiled path needs the pass
@@ -907,8 +1530,14 @@ int bwd_t(const AttnParams& p, hipStream_t s) {
 }  // namespace
 
 void attn_set_force_tiled(int on) { g_attn_force_tiled = on; }
+void attn_set_variant(int v) { g_attn_variant = v; }
 
-int launch_attn_fwd(const AttnParams& p, hipStream_t s) {
+int g_attn_dbg = 0;
+void attn_set_dbg(int v) { g_attn_dbg = v; }
+
+int launch_attn_fwd(const AttnParams& p_in, hipStream_t s) {
+  AttnParams p = p_in;
+  p.dbg = g_attn_dbg;
   int rc = check(p);
   if (rc) return rc;
   switch (p.dh) {

@@ -1214,6 +1214,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     gemm_set_big_impl(value);
     return 0;
   }
+  if (!strcmp(key, "attn_variant")) {  // process-wide: 0 streaming attention kernels, 1 round-1 resident / tiled
+    attn_set_variant(value);
+    return 0;
+  }
   if (!strcmp(key, "tn_loop")) {  // process-wide: main loop of the grouped wgrad kernel (gemm_set_tn_cfg)
     gemm_set_tn_cfg(value);
     return 0;
@@ -1723,6 +1727,11 @@ int fact_debug_force_generic_gemm(int on) {
 }
 int fact_debug_attn_force_tiled(int on) {
   attn_set_force_tiled(on);
+  return 0;
+}
+int fact_debug_attn_variant(int v) {
+  attn_set_variant(v & 0xff);
+  attn_set_dbg(v >> 8);
   return 0;
 }
 int fact_debug_gemm_nt_variant(int v) {
