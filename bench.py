@@ -211,6 +211,9 @@ def run_scaled(args, device):
              "audio_input": torch.randn(B, 960, 35, generator=gen).to(device),
              "target": torch.randn(B, TARGET_LEN, 225, generator=gen).to(device)}
     model.build(B, 225, 35)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        model.set_option(k, int(v))
     nparams = sum(int(v.numel()) for v in model.trainable_variables)
 
     class Repeat:

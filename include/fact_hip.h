@@ -197,9 +197,12 @@ int fact_probe_tr(const float* lds_vals, int n, const int* byte_addrs, float* ou
 int fact_debug_force_generic_gemm(int on);
 /* Test knob: 1 = use the tiled (streaming) attention kernels even when the LDS-resident ones fit. */
 int fact_debug_attn_force_tiled(int on);
-/* Test/bench knob: attention kernel family. 0 = streaming 4-wave kernels (default), 1 = round-1 dispatch
- * (one workgroup per (batch, head) with K/V resident in LDS when they fit, tiled kernels otherwise). */
+/* Test/bench knob: attention kernel family. 1 (default) = one workgroup per (batch, head) with K/V resident in
+ * LDS when they fit, tiled kernels otherwise; 2 = streaming 4-wave kernels (128-row blocks, LDS-DMA ring). */
 int fact_debug_attn_variant(int v);
+/* Bench only: device buffer of u64[B*H][waves][8] that receives per-wave s_memtime stamps of the LDS-resident
+ * forward attention kernel (null = off). */
+int fact_debug_attn_timestamps(void* buf);
 /* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 6 / 7 = big-tile 288x256 / 256x256). */
 int fact_debug_gemm_splitk_max(int v); /* in-kernel split-K slices of the N = 800 GEMMs (1 = off, default 4) */
 int fact_debug_gemm_tn_cfg(int v); /* grouped wgrad tile: 0 = 160x256, 1 = 160x384 */

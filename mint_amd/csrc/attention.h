@@ -27,11 +27,11 @@ struct AttnParams {
   int B, H, n, NP, hid, dh;
   int ldo, ldq;       // row pitches (elements) of out/o and of dqkv (>= hid, >= 3*hid)
   float scale;
-  int dbg;            // timing ablations of the streaming forward kernel (bench only; 0 in the product)
+  unsigned long long* ts;  // bench only: per-wave s_memtime stamps of the resident forward kernel (null = off)
 };
 
 int launch_attn_fwd(const AttnParams& p, hipStream_t s);
 int launch_attn_bwd(const AttnParams& p, hipStream_t s);  // prep + dQ + dKdV
-void attn_set_variant(int v);  // 0 = streaming kernels (default), 1 = round-1 dispatch (LDS-resident / tiled)
+void attn_set_variant(int v);  // 1 = LDS-resident / tiled kernels (default), 2 = streaming 4-wave kernels
 void attn_set_force_tiled(int on);
-void attn_set_dbg(int v);  // bench only: timing ablation bits of the streaming forward kernel  // test knob: 1 = tiled (streaming) kernels even when the LDS-resident ones fit
+void attn_set_ts(unsigned long long* buf);  // bench only: timestamp buffer, [B*H][waves][8]  // bench only: timing ablation bits of the streaming forward kernel  // test knob: 1 = tiled (streaming) kernels even when the LDS-resident ones fit

@@ -488,6 +488,11 @@ __global__ __launch_bounds__(768) void attn_fwd_res_kernel(const AttnParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, g = lane >> 4;
   const int bh = blockIdx.x;
+  unsigned long long* ts = p.ts ? p.ts + ((size_t)bh * nw + wave) * 8 : nullptr;
+  auto stamp = [&](int i) {
+    if (ts && lane == 0) ts[i] = __builtin_readcyclecounter();
+  };
+  stamp(0);
   const int rows = (p.n + 31) & ~31;
   unsigned char* Kimg = smem;
   unsigned char* Vimg = smem + (((size_t)rows * G::DHP * 2 + 1023) & ~(size_t)1023);
@@ -512,12 +517,17 @@ __global__ __launch_bounds__(768) void attn_fwd_res_kernel(const AttnParams p) {
 #pragma unroll
     for (int dt = 0; dt < G::ND; ++dt) O[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  stamp(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(2);
   __syncthreads();
+  stamp(3);
 
   const float sc = p.scale * LOG2E;
   const int nkt = rows >> 5;
   for (int kt = 0; kt < nkt; ++kt) {
+    if (kt == 1) stamp(4);
+    if (kt == nkt / 2) stamp(5);
     f32x4 s[2][2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -578,6 +588,7 @@ __global__ __launch_bounds__(768) void attn_fwd_res_kernel(const AttnParams p) {
       for (int qs = 0; qs < 2; ++qs) O[qs][dt] = mfma16(vf, pb[qs], O[qs][dt]);
     }
   }
+  stamp(6);
   const int b = bh / p.H, h = bh - b * p.H;
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs) {
@@ -596,6 +607,10 @@ __global__ __launch_bounds__(768) void attn_fwd_res_kernel(const AttnParams p) {
         *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
       }
     }
+  }
+  if (ts) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(7);
   }
 }
 
@@ -977,18 +992,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p)
   const size_t row_base = (size_t)bh * p.NP * G::DHP;
   const int q0 = blockIdx.x * 128 + wave * 32;
   const bool active = q0 < p.n;  // wave-uniform; inactive waves still stage and synchronise
-  if (p.dbg & 512) return;
 
   bf16x8 Qf[2][G::KD];
 #pragma unroll
   for (int qs = 0; qs < 2; ++qs)
 #pragma unroll
-    for (int kd = 0; kd < G::KD; ++kd) {
-      Qf[qs][kd] = zero_bf16x8();
-      if (!(p.dbg & 256))
+    for (int kd = 0; kd < G::KD; ++kd)
       Qf[qs][kd] = *reinterpret_cast<const bf16x8*>(
           p.qrow + row_base + (size_t)(q0 + qs * 16 + (lane & 15)) * G::DHP + kd * 32 + g * 8);
-    }
   StDma<DH> dma;
   st_dma_init<DH>(dma, p.krow + row_base, p.vrow + row_base, wave, lane);
   st_dma_issue<DH>(dma, smem, 0);
@@ -1013,13 +1024,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p)
     ones = bf16x8{one, one, one, one, one, one, one, one};
   }
   const float sc = p.scale * LOG2E;
-  const int dbg = p.dbg;
 
   auto body = [&](auto slot_c, int kt) {
     constexpr int SLOT = decltype(slot_c)::value;
     st_wait_vm<2 * PPW>();
-    if (!(dbg & 16)) __builtin_amdgcn_s_barrier();
-    if (!(dbg & 1)) st_dma_issue<DH>(dma, smem + ((SLOT + 3) & 3) * STAGE, min(kt + 3, T - 1));
+    __builtin_amdgcn_s_barrier();
+    st_dma_issue<DH>(dma, smem + ((SLOT + 3) & 3) * STAGE, min(kt + 3, T - 1));
     if (!active) return;
     const unsigned char* Kimg = smem + SLOT * STAGE;
     f32x4 s[2][2];
@@ -1027,7 +1037,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p)
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int qs = 0; qs < 2; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (!(dbg & 4)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1036,14 +1045,9 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p)
 #pragma unroll
         for (int qs = 0; qs < 2; ++qs) s[ks][qs] = mfma16(kf, Qf[qs][kd], s[ks][qs]);
       }
-    }
     // V^T fragments of this stage: issued now, consumed after the softmax
     bf16x4 vlo[ND], vhi[ND];
-    if (!(dbg & 64)) st_tr_all<DH, SLOT * STAGE + IMG, 0>(va, vlo, vhi);
-    else {
-#pragma unroll
-      for (int dt = 0; dt < ND; ++dt) { vlo[dt] = bf16x4{}; vhi[dt] = bf16x4{}; }
-    }
+    st_tr_all<DH, SLOT * STAGE + IMG, 0>(va, vlo, vhi);
     if (kt == T - 1 && (p.n & 31)) {  // padded keys only exist in the last tile (wave-uniform)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
@@ -1089,17 +1093,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p)
       f32x4 p0, p1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        p0[r] = (dbg & 2) ? t[qs][r] : __builtin_amdgcn_exp2f(t[qs][r]);
-        p1[r] = (dbg & 2) ? t[qs][4 + r] : __builtin_amdgcn_exp2f(t[qs][4 + r]);
+        p0[r] = __builtin_amdgcn_exp2f(t[qs][r]);
+        p1[r] = __builtin_amdgcn_exp2f(t[qs][4 + r]);
       }
       pb[qs] = pack8(p0, p1);
     }
     st_tr_retire<ND>(vlo, vhi);
-    if (dbg & 8) {
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) O[qs][0][0] += (float)pb[qs][0] + (float)vlo[0][0];
-      return;
-    }
 #pragma unroll
     for (int dt = 0; dt < ND; ++dt) {
       const bf16x8 vf = cat4(vlo[dt], vhi[dt]);
@@ -1109,7 +1108,6 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p)
 #pragma unroll
     for (int qs = 0; qs < 2; ++qs) O[qs][ND] = mfma16(ones, pb[qs], O[qs][ND]);
   };
-  if (!(p.dbg & 1024))
   for (int kt = 0; kt < T; kt += 4) {
     body(SlotK<0>{}, kt);
     if (kt + 1 < T) body(SlotK<1>{}, kt + 1);
@@ -1126,7 +1124,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p)
     const float inv = 1.0f / lt;
     const int t = q0 + qs * 16 + (lane & 15);
     if (g == 0 && t < p.NP) p.lse2[(size_t)bh * p.NP + t] = m[qs] + __log2f(lt);
-    if (t < p.n && (!(p.dbg & 128) || lt == 12345.f)) {
+    if (t < p.n) {
       bf16_t* orow = p.out + ((size_t)b * p.n + t) * p.ldo + h * DH + g * 4;
 #pragma unroll
       for (int dt = 0; dt < ND; ++dt) {
@@ -1180,6 +1178,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_st_kernel(const AttnParams
   StDma<DH> dma;
   st_dma_init<DH>(dma, p.krow + row_base, p.vrow + row_base, wave, lane);
   st_wait_vm<0>();  // the operand loads above: the counted waits below then only see DMA pieces
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    asm volatile("" : "+v"(L2q[qs]), "+v"(Dq[qs]));
+#pragma unroll
+    for (int kd = 0; kd < G::KD; ++kd) asm volatile("" : "+v"(Qf[qs][kd]), "+v"(dOf[qs][kd]));
+  }
   st_dma_issue<DH>(dma, smem, 0);
   st_dma_issue<DH>(dma, smem + STAGE, min(1, T - 1));
   st_dma_issue<DH>(dma, smem + 2 * STAGE, min(2, T - 1));
@@ -1423,7 +1427,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_st_kernel(const AttnPara
   }
 }
 
-int g_attn_variant = 0;  // 0 = streaming family (default), 1 = round-1 dispatch (LDS-resident when it fits, else tiled)
+int g_attn_variant = 1;  // 1 = LDS-resident kernels when the head fits, tiled otherwise (default: measured equal or better in the train step); 2 = streaming family
 int g_attn_force_tiled = 0;  // test knob: 1 = always use the tiled (streaming) kernels
 
 // LDS bytes of the resident kernels for n tokens; 0 = does not fit -> tiled kernels
@@ -1473,7 +1477,7 @@ int allow_lds_bytes(K kernel, bool* done, size_t bytes) {
 
 template <int DH>
 int fwd_t(const AttnParams& p, hipStream_t s) {
-  if (g_attn_variant == 0 && !g_attn_force_tiled) {
+  if (g_attn_variant == 2 && !g_attn_force_tiled) {
     constexpr size_t lds = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG;
     static bool attr = false;
     if (int rc = allow_lds_bytes(attn_fwd_st_kernel<DH>, &attr, lds)) return rc;
@@ -1494,7 +1498,7 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
 }
 template <int DH>
 int bwd_t(const AttnParams& p, hipStream_t s) {
-  if (g_attn_variant == 0 && !g_attn_force_tiled) {
+  if (g_attn_variant == 2 && !g_attn_force_tiled) {
     constexpr size_t lds1 = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG, lds2 = (size_t)SG<DH>::NSLOT * (2 * SG<DH>::IMG + 256);
     static bool attr1 = false, attr2 = false;
     if (int rc = allow_lds_bytes(attn_bwd_dq_st_kernel<DH>, &attr1, lds1)) return rc;
@@ -1532,12 +1536,12 @@ int bwd_t(const AttnParams& p, hipStream_t s) {
 void attn_set_force_tiled(int on) { g_attn_force_tiled = on; }
 void attn_set_variant(int v) { g_attn_variant = v; }
 
-int g_attn_dbg = 0;
-void attn_set_dbg(int v) { g_attn_dbg = v; }
+unsigned long long* g_attn_ts = nullptr;
+void attn_set_ts(unsigned long long* buf) { g_attn_ts = buf; }
 
 int launch_attn_fwd(const AttnParams& p_in, hipStream_t s) {
   AttnParams p = p_in;
-  p.dbg = g_attn_dbg;
+  p.ts = g_attn_ts;
   int rc = check(p);
   if (rc) return rc;
   switch (p.dh) {

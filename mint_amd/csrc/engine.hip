@@ -1214,7 +1214,7 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     gemm_set_big_impl(value);
     return 0;
   }
-  if (!strcmp(key, "attn_variant")) {  // process-wide: 0 streaming attention kernels, 1 round-1 resident / tiled
+  if (!strcmp(key, "attn_variant")) {  // process-wide: 1 LDS-resident / tiled attention kernels (default), 2 streaming
     attn_set_variant(value);
     return 0;
   }
@@ -1729,9 +1729,12 @@ int fact_debug_attn_force_tiled(int on) {
   attn_set_force_tiled(on);
   return 0;
 }
+int fact_debug_attn_timestamps(void* buf) {
+  attn_set_ts((unsigned long long*)buf);
+  return 0;
+}
 int fact_debug_attn_variant(int v) {
-  attn_set_variant(v & 0xff);
-  attn_set_dbg(v >> 8);
+  attn_set_variant(v);
   return 0;
 }
 int fact_debug_gemm_nt_variant(int v) {

@@ -371,12 +371,16 @@ def _attn_ref(qkv, B, H, n, dh, scale, dout=None):
     return out.detach(), x.grad
 
 
-@pytest.fixture(params=[0, 1], ids=["resident", "tiled"])
+@pytest.fixture(params=[0, 1, 2], ids=["resident", "tiled", "streaming"])
 def attn_path(request):
-    """LDS-resident kernels (when they fit) and the tiled streaming kernels."""
-    L.lib().fact_debug_attn_force_tiled(request.param)
+    """The three kernel families: LDS-resident (when the head fits), tiled, and the streaming 4-wave kernels
+    (128-row blocks, 4-slot LDS-DMA ring, lazy-max softmax with MFMA row sums)."""
+    lib = L.lib()
+    lib.fact_debug_attn_force_tiled(1 if request.param == 1 else 0)
+    lib.fact_debug_attn_variant(2 if request.param == 2 else 1)
     yield request.param
-    L.lib().fact_debug_attn_force_tiled(0)
+    lib.fact_debug_attn_force_tiled(0)
+    lib.fact_debug_attn_variant(1)
 
 
 @pytest.mark.parametrize("B,H,n,dh", [(2, 4, 32, 32), (1, 2, 96, 64), (2, 10, 360, 80), (2, 10, 120, 80),
