@@ -27,6 +27,9 @@ struct AttnParams {
   int B, H, n, NP, hid, dh;
   int ldo, ldq;       // row pitches (elements) of out/o and of dqkv (>= hid, >= 3*hid)
   float scale;
+  int nq;             // > 0: only query rows t < nq matter (supervised-rows shortcut of the last layer): forward computes
+                      // those rows only; backward treats dO rows >= nq as zero (the LDS-resident kernels skip the work,
+                      // the other families rely on the caller having zeroed those dO rows)
   unsigned long long* ts;  // bench only: per-wave s_memtime stamps of the resident forward kernel (null = off)
 };
 

@@ -522,6 +522,7 @@ __global__ __launch_bounds__(768) void attn_fwd_res_kernel(const AttnParams p) {
   stamp(2);
   __syncthreads();
   stamp(3);
+  if (p.nq > 0 && q0 >= p.nq) return;  // supervised-rows shortcut: no barrier follows, the wave can leave
 
   const float sc = p.scale * LOG2E;
   const int nkt = rows >> 5;
@@ -629,6 +630,21 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_res_kernel(const AttnParams p
 
   const int q0 = wave * 32;
   const int b = bh / p.H, h = bh - b * p.H;
+  if (p.nq > 0 && q0 >= p.nq) {
+    // supervised-rows shortcut: dO is zero on these query rows, so is dQ (the QKV dgrad reads every row)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const int t = q0 + qs * 16 + (lane & 15);
+      if (t < p.n) {
+        bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * p.ldq + h * DH + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt) *reinterpret_cast<bf16x4*>(orow + dt * 16) = bf16x4{};
+      }
+    }
+    return;
+  }
   bf16x8 Qf[2][G::KD], dOf[2][G::KD];
   float L2q[2], Dq[2];
 #pragma unroll
@@ -749,6 +765,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_res_kernel(const AttnParams
 
   const float sc = p.scale * LOG2E;
   const int nqt = rows >> 5;
+  const int nqv = (p.nq > 0 && p.nq < p.n) ? p.nq : p.n;  // valid query rows (supervised-rows shortcut: dO rows >= nq are zero)
+  const int nqt_eff = (nqv + 31) >> 5;
   const int b = bh / p.H, h = bh - b * p.H;
   for (int slot = wave; slot < nqt; slot += nw) {
     const int key0 = slot * 32;
@@ -772,7 +790,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_res_kernel(const AttnParams
     bool kvalid[2];
     kvalid[0] = (key0 + (lane & 15)) < p.n;
     kvalid[1] = (key0 + 16 + (lane & 15)) < p.n;
-    for (int qt = 0; qt < nqt; ++qt) {
+    for (int qt = 0; qt < nqt_eff; ++qt) {
       f32x4 s[2][2], dp[2][2];  // [qsub][ksub]
 #pragma unroll
       for (int qs = 0; qs < 2; ++qs)
@@ -804,7 +822,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_res_kernel(const AttnParams
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           // padded keys AND padded query rows are masked (shared dO scratch: see the tiled kernel)
-          const bool qv0 = (qt * 32 + g * 4 + r) < p.n, qv1 = (qt * 32 + 16 + g * 4 + r) < p.n;
+          const bool qv0 = (qt * 32 + g * 4 + r) < nqv, qv1 = (qt * 32 + 16 + g * 4 + r) < nqv;
           p0[r] = (kvalid[ks] && qv0) ? __builtin_amdgcn_exp2f(fmaf(s[0][ks][r], sc, -l2a[r])) : 0.f;
           p1[r] = (kvalid[ks] && qv1) ? __builtin_amdgcn_exp2f(fmaf(s[1][ks][r], sc, -l2b[r])) : 0.f;
           d0[r] = p0[r] * (dp[0][ks][r] - dda[r]);

@@ -121,11 +121,28 @@ constexpr int kBwBuf = 3;  // layer-parity depth of every buffer the wgrad strea
 // end of the layer's dgrad chain and launched on the wgrad stream a little later (flush_batch).
 struct PendingBatch {
   bool valid = false;
+  int sr_rows = 0, sr_pad = 0;  // > 0: supervised-rows layer - the compact buffers of SrBuf hold dpre / xmid16 / xin16 / dh2
+  int sr_B = 0, sr_T = 0;
   Stack* st = nullptr;
   int l = 0, M = 0, q = 0;
   const bf16_t *xin16 = nullptr, *dpre = nullptr, *xmid16 = nullptr, *dqkv = nullptr, *dh2 = nullptr, *dh1 = nullptr;
   hipStream_t s = nullptr, w = nullptr;
   float* slab = nullptr;
+};
+
+// Supervised-rows shortcut (training only).  The loss reads the first T output tokens of every sequence
+// (fact_model.py:143-148), so in the LAST cross-modal layer only those B*T rows are needed after the attention's
+// K/V projections: attention queries, to_out, LayerNorm 2, the MLP and the head run on a compact (B*T)-row copy,
+// and in backward the same rows carry all of the gradient (everything else of dL/dx_out is exactly zero), so the
+// MLP / to_out dgrads and the weight gradients of W2, W1, Wo contract over B*T instead of B*n tokens.  Loss and
+// every gradient are those of the full computation up to fp32 summation order; fact_forward (inference, all n
+// rows returned) never takes the shortcut.  Rows are padded to a multiple of 64 with zero rows (wgrad K).
+struct SrBuf {
+  bf16_t *a_c = nullptr, *h2_c = nullptr, *pre_c = nullptr, *g_c = nullptr, *xf16_c = nullptr;
+  bf16_t *dx16_c = nullptr, *dpre_c = nullptr, *dh2_c = nullptr, *xmid16_c = nullptr, *dpred_c = nullptr;
+  float *x_in_c = nullptr, *x_mid_c = nullptr, *x_out_c = nullptr, *mean2_c = nullptr, *rstd2_c = nullptr;
+  float *pred_c = nullptr, *dx_c = nullptr;
+  int rows_max = 0;
 };
 
 struct BwScratch {
@@ -220,6 +237,10 @@ struct FactHandle {
   int wgrad_parts = 2;   // launches per layer of the grouped wgrad kernel (each ~190/parts workgroups wide)
   int wgrad_defer = 1;   // release a layer's wgrad batch behind the NEXT layer's GELU' dgrad (240 workgroups)
   int bwd_splitk = 0;    // in-kernel split-K for the N = 800 dgrad GEMMs (they share the chip with the wgrad launches)
+  int sr_rows = 1;       // supervised-rows shortcut of the last cross-modal layer in fact_forward_backward (SrBuf)
+  SrBuf sr;
+  float* skinny_acc = nullptr;  // zero-filled fp32 accumulator of the skinny-M GEMMs of that layer (caller's stream)
+  size_t skinny_floats = 0;
   float* slab = nullptr;  // split-K partial slabs of the wgrad GEMM running on the side stream
   // second stream: wgrad GEMMs run beside the dgrad chain, the audio encoder beside the motion encoder
   int use_side = 1;
@@ -456,6 +477,19 @@ void layout_work(FactHandle* h, Bump& b) {
       if (BH * st->NP * st->dhp > rowmax) rowmax = BH * st->NP * st->dhp;
       if (BH * st->NP > lsemax) lsemax = BH * st->NP;
     }
+    {  // supervised-rows compact buffers: up to 32 target rows per sequence
+      SrBuf& r = h->sr;
+      const size_t R = rups((size_t)B * 32, 64);
+      const int fpc = h->cross.fp;
+      r.rows_max = (int)R;
+      r.a_c = b.take<bf16_t>(R * dp); r.h2_c = b.take<bf16_t>(R * dp); r.pre_c = b.take<bf16_t>(R * fpc);
+      r.g_c = b.take<bf16_t>(R * fpc); r.xf16_c = b.take<bf16_t>(R * dp); r.dx16_c = b.take<bf16_t>(R * dp);
+      r.dpre_c = b.take<bf16_t>(R * fpc); r.dh2_c = b.take<bf16_t>(R * dp); r.xmid16_c = b.take<bf16_t>(R * dp);
+      r.dpred_c = b.take<bf16_t>(R * h->outp);
+      r.x_in_c = b.take<float>(R * d); r.x_mid_c = b.take<float>(R * d); r.x_out_c = b.take<float>(R * d);
+      r.mean2_c = b.take<float>(R); r.rstd2_c = b.take<float>(R);
+      r.pred_c = b.take<float>(R * h->cfg.out_dim); r.dx_c = b.take<float>(R * d);
+    }
     h->dpred = b.take<bf16_t>(Mc * h->outp);
     h->dx = b.take<float>(Mc * d);
     h->dx16 = b.take<bf16_t>(Mc * dp);
@@ -636,6 +670,12 @@ void with_ws(FactHandle* h, GemmParams& g, hipStream_t s) {
   g.sk_cnt = h->sk_cnt[i];
 }
 
+// hand the zero-filled skinny-M accumulator to a GEMM of the supervised-rows layer (caller's stream only)
+void with_skinny(FactHandle* h, GemmParams& g) {
+  g.skinny_acc = h->skinny_acc;
+  g.skinny_floats = h->skinny_floats;
+}
+
 // dW[Mo][No] += A^T B ; A [K][Mo(lda)], B [K][No(ldb)]
 int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int ldb, int No, int K,
           float* out, int ldo, hipStream_t s, float* slab = nullptr) {
@@ -782,6 +822,64 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
   return 0;
 }
 
+// Forward of the LAST cross-modal layer with the supervised-rows shortcut (SrBuf): LayerNorm 1 and the QKV
+// projection on all rows (every key / value is needed), attention for the first T queries of each sequence, then
+// to_out, LayerNorm 2, the MLP on the compact B*T rows.  The layer output exists only as sr.x_out_c.
+int layer_forward_sr(FactHandle* h, Stack& st, int l, int B, int T, hipStream_t s) {
+  const int M = B * st.n, Mr = B * T, d = st.d, dp = st.dp, fp = st.fp;
+  LayerP& p = st.lp[l];
+  LayerA& a = st.la[l];
+  SrBuf& r = h->sr;
+  const double Md = (double)M, Mrd = (double)Mr;
+  {
+    KScope k(h, KP_LN_FWD, s, 0, Md * d * 6.0);
+    CHK(launch_ln_fwd(a.x_in, P(h, p.ln1_g), P(h, p.ln1_b), a.h1, dp, a.mean1, a.rstd1, M, d, h->cfg.ln_eps, s));
+  }
+  {
+    KScope k(h, KP_QKV, s, 2.0 * Md * 3 * d * d);
+    GemmParams g = gp(a.h1, dp, p.wqkv.t, p.wqkv.ldt, M, 3 * d, d);
+    heads_ep(g.ep, st, a.row, 3);
+    with_ws(h, g, s);
+    CHK(launch_gemm_nt(EPI_HEADS, g, s));
+  }
+  {
+    KScope k(h, KP_ATTN_FWD, s, 4.0 * (double)B * st.H * (double)T * st.n * st.dh);
+    AttnParams ap = attn_params(st, a, B);
+    ap.nq = T;
+    CHK(launch_attn_fwd(ap, s));
+  }
+  CHK(launch_gather_rows(a.x_in, a.a, B, st.n, T, d, dp, r.x_in_c, r.a_c, s));
+  {
+    KScope k(h, KP_OUTPROJ, s, 2.0 * Mrd * d * d);
+    GemmParams g = gp(r.a_c, dp, p.wo.t, p.wo.ldt, Mr, d, d);
+    with_skinny(h, g);
+    g.ep.out0 = r.x_mid_c; g.ep.ldo0 = d; g.ep.bias = P(h, p.bo); g.ep.resid = r.x_in_c; g.ep.ldr = d;
+    with_ws(h, g, s);
+    CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
+  }
+  {
+    KScope k(h, KP_LN_FWD, s, 0, Mrd * d * 6.0);
+    CHK(launch_ln_fwd(r.x_mid_c, P(h, p.ln2_g), P(h, p.ln2_b), r.h2_c, dp, r.mean2_c, r.rstd2_c, Mr, d, h->cfg.ln_eps, s));
+  }
+  {
+    KScope k(h, KP_FFN1, s, 2.0 * Mrd * st.ff * d);
+    GemmParams g = gp(r.h2_c, dp, p.w1.t, p.w1.ldt, Mr, st.ff, d);
+    with_skinny(h, g);
+    g.ep.out0 = r.pre_c; g.ep.ldo0 = fp; g.ep.out1 = r.g_c; g.ep.ldo1 = fp; g.ep.bias = P(h, p.b1);
+    with_ws(h, g, s);
+    CHK(launch_gemm_nt(EPI_BIAS_GELU, g, s));
+  }
+  {
+    KScope k(h, KP_FFN2, s, 2.0 * Mrd * st.ff * d);
+    GemmParams g = gp(r.g_c, fp, p.w2.t, p.w2.ldt, Mr, d, st.ff);
+    with_skinny(h, g);
+    g.ep.out0 = r.x_out_c; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = r.x_mid_c; g.ep.ldr = d;
+    with_ws(h, g, s);
+    CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
+  }
+  return 0;
+}
+
 // Launch the pending optimizer-only batch of a backward chain on its wgrad stream: the four weight gradients
 // (grouped whole-K launch in `wgrad_parts` pieces), the dense_1 bias and, with the split LayerNorm backward,
 // the LayerNorm / output-bias gradients of both sub-blocks - all behind ONE event recorded on the chain.
@@ -796,6 +894,61 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
   hipStream_t s = b.s, w = b.w;
   const bool two = (w != s);
   hipEvent_t rel = two ? stream_after(h, s, w) : nullptr;
+  if (b.sr_rows > 0) {
+    // supervised-rows layer: dW2, dW1, dWo contract over the compact (zero-padded) rows, dWqkv over all tokens
+    SrBuf& r = h->sr;
+    const int Mr = b.sr_rows, Kc = b.sr_pad;
+    {
+      KScope k(h, KP_WGRAD, w, 2.0 * ((double)Mr * ((double)d * ff * 2 + (double)d * d) + (double)M * d * d * 3), 0, 2);
+      bool grouped = h->wgrad_big && h->wgrad_tr && !(M & 31) && M >= 512 && !(d & 3) && !(ff & 3) && d >= 160;
+      if (grouped) {
+        TnGroup g;
+        memset(&g, 0, sizeof(g));
+        auto set = [&](int i, const bf16_t* A, int lda, int Mo, const bf16_t* Bm, int ldb, int No, float* out, int ldo,
+                       int trans) {
+          TnProblem& q = g.p[i];
+          q.A = A; q.lda = lda; q.M = Mo; q.B = Bm; q.ldb = ldb; q.N = No; q.out = out; q.ldo = ldo; q.trans_out = trans;
+        };
+        g.n = 3;
+        g.K = Kc;
+        set(0, r.dx16_c, dp, d, r.g_c, fp, ff, G(h, p.w2.w), d, 1);
+        set(1, r.h2_c, dp, d, r.dpre_c, fp, ff, G(h, p.w1.w), ff, 0);
+        set(2, r.a_c, dp, d, r.xmid16_c, dp, d, G(h, p.wo.w), d, 0);
+        CHK(launch_big_tn_group(g, w, 1));
+        memset(&g, 0, sizeof(g));
+        g.n = 1;
+        g.K = M;
+        set(0, a.h1, dp, d, b.dqkv, qp, 3 * d, G(h, p.wqkv.w), 3 * d, 0);
+        CHK(launch_big_tn_group(g, w, 1));
+      } else {
+        CHK(wgrad(h, r.g_c, fp, ff, r.dx16_c, dp, d, Kc, G(h, p.w2.w), d, w, b.slab));
+        CHK(wgrad(h, r.h2_c, dp, d, r.dpre_c, fp, ff, Kc, G(h, p.w1.w), ff, w, b.slab));
+        CHK(wgrad(h, r.a_c, dp, d, r.xmid16_c, dp, d, Kc, G(h, p.wo.w), d, w, b.slab));
+        CHK(wgrad(h, a.h1, dp, d, b.dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w, b.slab));
+      }
+    }
+    {
+      KScope kpg(h, KP_PARAM_GRADS, w, 0, (double)Mr * (ff * 2.0 + d * 12.0) + (double)M * d * 6.0, 2);
+      ColTasks ts;
+      memset(&ts, 0, sizeof(ts));
+      ts.n = 3;
+      ts.M = Mr;  // compact rows: dense_1 bias, LayerNorm 2 (+ dense_2 bias), to_out bias
+      ts.t[0].dy = r.dpre_c; ts.t[0].ldy = fp; ts.t[0].dbias = G(h, p.b1); ts.t[0].C = ff;
+      ts.t[1].dh = r.dh2_c; ts.t[1].ld16 = dp; ts.t[1].x = r.x_mid_c; ts.t[1].mean = r.mean2_c; ts.t[1].rstd = r.rstd2_c;
+      ts.t[1].dy = r.dx16_c; ts.t[1].ldy = dp; ts.t[1].dgamma = G(h, p.ln2_g); ts.t[1].dbeta = G(h, p.ln2_b);
+      ts.t[1].dbias = G(h, p.b2); ts.t[1].C = d;
+      ts.t[2].dy = r.xmid16_c; ts.t[2].ldy = dp; ts.t[2].dbias = G(h, p.bo); ts.t[2].C = d;
+      CHK(launch_col_tasks(ts, w));
+      memset(&ts, 0, sizeof(ts));
+      ts.n = 1;
+      ts.M = M;  // all rows: LayerNorm 1
+      ts.t[0].dh = b.dh1; ts.t[0].ld16 = dp; ts.t[0].x = a.x_in; ts.t[0].mean = a.mean1; ts.t[0].rstd = a.rstd1;
+      ts.t[0].dgamma = G(h, p.ln1_g); ts.t[0].dbeta = G(h, p.ln1_b); ts.t[0].C = d;
+      CHK(launch_col_tasks(ts, w));
+    }
+    if (two) sc.ev_batch[b.q] = stream_mark(h, w);
+    return 0;
+  }
   {
     KScope k(h, KP_WGRAD, w, 2.0 * (double)M * ((double)d * ff * 2 + (double)d * d * 4), 0,
              h->wgrad_big ? h->wgrad_parts : 8);
@@ -924,6 +1077,7 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   {
     PendingBatch& b = sc.pend;
     b.valid = true; b.st = &st; b.l = l; b.M = M; b.q = q;
+    b.sr_rows = 0; b.sr_pad = 0;
     b.xin16 = xin16; b.dpre = dpre; b.xmid16 = xmid16; b.dqkv = dqkv; b.dh2 = dh2; b.dh1 = dh1;
     b.s = s; b.w = w; b.slab = inl ? sc.slab : nullptr;
     if (!h->wgrad_defer) CHK(flush_batch(h, sc));
@@ -937,6 +1091,99 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   else
     CHK(launch_ln_bwd(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, G(h, p.ln1_g),
                       G(h, p.ln1_b), G(h, p.bo), sc.ln_ws, M, d, dp, s));
+  dx16 = xout16;
+  return 0;
+}
+
+// Backward of the LAST cross-modal layer with the supervised-rows shortcut: on entry sr.dx_c / sr.dx16_c hold
+// dL/dx_out of the B*T supervised rows (all other rows are exactly zero); on exit h->dx / dx16 hold dL/dx_in of
+// all rows, as after layer_backward.
+int layer_backward_sr(FactHandle* h, Stack& st, int l, int B, int T, float* dx, bf16_t*& dx16, hipStream_t s,
+                      BwScratch& sc) {
+  const int M = B * st.n, Mr = B * T, Kc = (int)rups((size_t)Mr, 64), d = st.d, ff = st.ff, dp = st.dp, fp = st.fp,
+            qp = st.qp;
+  LayerP& p = st.lp[l];
+  LayerA& a = st.la[l];
+  SrBuf& r = h->sr;
+  hipStream_t w = side_of(h, s);
+  const bool two = (w != s);
+  const int q = (int)(sc.bw_i++ % kBwBuf);
+  bf16_t* dqkv = sc.dqkv_pp[q];
+  bf16_t* xout16 = sc.xb_pp[q];
+  bf16_t* dh1 = h->ln_split ? sc.dh1_pp[q] : sc.dh;
+  if (two && sc.ev_batch[q]) (void)hipStreamWaitEvent(s, sc.ev_batch[q], 0);
+  const double Md = (double)M, Mrd = (double)Mr;
+  if (Kc > Mr) {  // zero pad rows of every wgrad operand (a smaller batch may have left data there)
+    const size_t nr = (size_t)(Kc - Mr);
+    HIPCHK(hipMemsetAsync(r.dx16_c + (size_t)Mr * dp, 0, nr * dp * 2, s));
+    HIPCHK(hipMemsetAsync(r.g_c + (size_t)Mr * fp, 0, nr * fp * 2, s));
+    HIPCHK(hipMemsetAsync(r.h2_c + (size_t)Mr * dp, 0, nr * dp * 2, s));
+    HIPCHK(hipMemsetAsync(r.dpre_c + (size_t)Mr * fp, 0, nr * fp * 2, s));
+    HIPCHK(hipMemsetAsync(r.a_c + (size_t)Mr * dp, 0, nr * dp * 2, s));
+    HIPCHK(hipMemsetAsync(r.xmid16_c + (size_t)Mr * dp, 0, nr * dp * 2, s));
+  }
+  {
+    KScope k(h, KP_GELU_DGRAD, s, 2.0 * Mrd * ff * d);
+    GemmParams g = gp(r.dx16_c, dp, p.w2.s, p.w2.lds, Mr, ff, d);
+    with_skinny(h, g);
+    g.ep.out0 = r.dpre_c; g.ep.ldo0 = fp; g.ep.pre = r.pre_c; g.ep.ldp = fp;
+    CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
+  }
+  CHK(flush_batch(h, sc));
+  {
+    KScope k(h, KP_DFFN1, s, 2.0 * Mrd * ff * d);
+    GemmParams g = gp(r.dpre_c, fp, p.w1.s, p.w1.lds, Mr, d, ff);
+    with_skinny(h, g);
+    g.ep.out0 = r.dh2_c; g.ep.ldo0 = dp;
+    CHK(launch_gemm_nt(EPI_BF16, g, s));
+  }
+  {
+    KScope k(h, KP_LN_BWD, s, 0, Mrd * d * 16.0);
+    if (h->ln_split)
+      CHK(launch_ln_bwd_dx(r.dh2_c, r.x_mid_c, r.mean2_c, r.rstd2_c, P(h, p.ln2_g), r.dx_c, r.dx_c, r.xmid16_c, Mr, d, dp, s));
+    else
+      return fail(-1, "supervised-rows shortcut needs ln_split");
+  }
+  // per-head dO rows: everything beyond the supervised rows must read as zero (all kernel families)
+  HIPCHK(hipMemsetAsync(sc.dorow, 0, (size_t)B * st.H * st.NP * st.dhp * sizeof(bf16_t), s));
+  {
+    KScope k(h, KP_OUT_DGRAD, s, 2.0 * Mrd * d * d);
+    GemmParams g = gp(r.xmid16_c, dp, p.wo.s, p.wo.lds, Mr, d, d);
+    with_skinny(h, g);
+    bf16_t* row[1] = {sc.dorow};
+    heads_ep(g.ep, st, row, 1);
+    g.ep.n_tok = T;  // compact row -> (b, t) with T rows per sequence
+    CHK(launch_gemm_nt(EPI_HEADS, g, s));
+  }
+  {
+    KScope k(h, KP_ATTN_BWD, s, 2.5 * 4.0 * (double)B * st.H * (double)T * st.n * st.dh, 0, 2);
+    AttnParams ap = attn_params(st, a, B);
+    ap.dorow = sc.dorow; ap.dsum = sc.dsum; ap.dqkv = dqkv;
+    ap.nq = T;
+    CHK(launch_attn_bwd(ap, s));
+  }
+  {
+    KScope k(h, KP_DQKV, s, 2.0 * Md * 3 * d * d);
+    GemmParams g = gp(dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
+    g.ep.out0 = dh1; g.ep.ldo0 = dp;
+    if (h->bwd_splitk) with_ws(h, g, s);
+    CHK(launch_gemm_nt(EPI_BF16, g, s));
+  }
+  // residual gradient of all rows: the compact rows scattered, zero elsewhere
+  CHK(launch_scatter_rows_zero(r.dx_c, B, st.n, T, d, dx, s));
+  {
+    PendingBatch& b = sc.pend;
+    b = PendingBatch();
+    b.valid = true; b.st = &st; b.l = l; b.M = M; b.q = q;
+    b.dqkv = dqkv; b.dh1 = dh1;
+    b.s = s; b.w = w; b.slab = nullptr;
+    b.sr_rows = Mr; b.sr_pad = Kc; b.sr_B = B; b.sr_T = T;
+    if (!h->wgrad_defer) CHK(flush_batch(h, sc));
+  }
+  const int qr = (q + 1) % kBwBuf;
+  if (two && sc.ev_batch[qr]) (void)hipStreamWaitEvent(s, sc.ev_batch[qr], 0);
+  KScope kln1(h, KP_LN_BWD, s, 0, Md * d * 16.0);
+  CHK(launch_ln_bwd_dx(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, M, d, dp, s));
   dx16 = xout16;
   return 0;
 }
@@ -974,7 +1221,7 @@ int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t widt
 
 // forward through both encoders and the cross-modal stack; final hidden states in cross.out()
 int model_forward_hidden(FactHandle* h, const float* motion, size_t m_stride, const float* audio,
-                         size_t a_stride, int B, hipStream_t s) {
+                         size_t a_stride, int B, hipStream_t s, int sr_T = 0) {
   Stack &mo = h->motion, &au = h->audio, &cr = h->cross;
   hipStream_t w = side_of(h, s);
   if (w != s) stream_after(h, s, w);
@@ -985,7 +1232,10 @@ int model_forward_hidden(FactHandle* h, const float* motion, size_t m_stride, co
   if (w != s) stream_after(h, w, s);
   // tf.concat([motion, audio], axis=1)  (base_models.py:192-193)
   CHK(launch_concat_seq(mo.out(), au.out(), B, mo.n, au.n, cr.d, cr.x0, s));
-  for (int l = 0; l < cr.L; ++l) CHK(layer_forward(h, cr, l, B, s));
+  for (int l = 0; l < cr.L; ++l) {
+    if (sr_T > 0 && l == cr.L - 1) CHK(layer_forward_sr(h, cr, l, B, sr_T, s));  // supervised rows only (training)
+    else CHK(layer_forward(h, cr, l, B, s));
+  }
   return 0;
 }
 
@@ -1123,6 +1373,13 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
     HIPCHK(hipMalloc((void**)&h->sk_cnt[i], kSplitKCounters * sizeof(unsigned)));
     HIPCHK(hipMemset(h->sk_cnt[i], 0, kSplitKCounters * sizeof(unsigned)));
   }
+  if (h->training) {
+    size_t wide = (size_t)h->cross.ff;
+    if ((size_t)3 * h->cross.d > wide) wide = (size_t)3 * h->cross.d;
+    h->skinny_floats = (size_t)512 * rups(wide, 4);
+    HIPCHK(hipMalloc((void**)&h->skinny_acc, h->skinny_floats * sizeof(float)));
+    HIPCHK(hipMemset(h->skinny_acc, 0, h->skinny_floats * sizeof(float)));
+  }
   h->ev.resize(1024);  // ~170 records per train step: a stored handle is never re-recorded before its use
   for (hipEvent_t& e : h->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   *out = h;
@@ -1146,6 +1403,7 @@ int fact_destroy(FactHandle* h) {
   if (h->opt) (void)hipStreamDestroy(h->opt);
   if (h->aux) (void)hipStreamDestroy(h->aux);
   if (h->lite) (void)hipStreamDestroy(h->lite);
+  (void)hipFree(h->skinny_acc);
   (void)hipFree(h->ar_motion);
   for (int i = 0; i < 3; ++i) {
     (void)hipFree(h->sk_slab[i]);
@@ -1230,6 +1488,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     h->wgrad_defer = value;
     return 0;
   }
+  if (!strcmp(key, "sr_rows")) {  // supervised-rows shortcut of the last cross-modal layer (training step)
+    h->sr_rows = value;
+    return 0;
+  }
   if (!strcmp(key, "bwd_splitk")) {
     h->bwd_splitk = value;
     return 0;
@@ -1279,23 +1541,56 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   if (T <= 0 || T > cr.n) return fail(-1, "target length outside (0, n_motion+n_audio]");
   hipStream_t s = (hipStream_t)stream;
   const int Mc = B * cr.n, d = cr.d, D = h->cfg.out_dim;
-  CHK(model_forward_hidden(h, motion, (size_t)mo.n * mo.feat, audio, (size_t)au.n * au.feat, B, s));
-  CHK(head_forward(h, B, h->pred, s));
-  // loss + dL/dpred
+  // supervised-rows shortcut (SrBuf): the last cross-modal layer and the head on the B*T rows the loss reads
+  const bool sr = h->sr_rows && h->ln_split && cr.L >= 1 && T <= 32 && 4 * T <= cr.n &&
+                  rups((size_t)B * T, 64) <= (size_t)h->sr.rows_max;
+  CHK(model_forward_hidden(h, motion, (size_t)mo.n * mo.feat, audio, (size_t)au.n * au.feat, B, s, sr ? T : 0));
   HIPCHK(hipMemsetAsync(h->scalars, 0, 16 * sizeof(float), s));
-  CHK(launch_mse_loss(h->pred, target, h->scalars, h->dpred, B, cr.n, T, D, h->outp, loss_scale, s));
-  if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, h->scalars, sizeof(float), hipMemcpyDeviceToDevice, s));
-  // head backward
-  {
-    hipStream_t w = side_of(h, s);
-    if (w != s) stream_after(h, s, w);
-    CHK(wgrad(h, h->xf16, cr.dp, d, h->dpred, h->outp, D, Mc, G(h, h->head.w), D, w));
-  }
-  CHK(launch_colsum_bf16(h->dpred, h->outp, G(h, h->head_b), Mc, h->outp, D, s));
-  {
-    GemmParams g = gp(h->dpred, h->outp, h->head.s, h->head.lds, Mc, d, h->outp);
-    g.ep.out0 = h->dx; g.ep.ldo0 = d; g.ep.out1 = h->dx16; g.ep.ldo1 = cr.dp;
-    CHK(launch_gemm_nt(EPI_F32_BF16, g, s));
+  if (sr) {
+    SrBuf& r = h->sr;
+    const int Mr = B * T, Kc = (int)rups((size_t)Mr, 64);
+    CHK(launch_pad_cast(r.x_out_c, Mr, 0, Mr, d, r.xf16_c, cr.dp, s));
+    {
+      GemmParams g = gp(r.xf16_c, cr.dp, h->head.t, h->head.ldt, Mr, D, d);
+      with_skinny(h, g);
+      g.ep.out0 = r.pred_c; g.ep.ldo0 = D; g.ep.bias = P(h, h->head_b);
+      CHK(launch_gemm_nt(EPI_F32_BIAS, g, s));
+    }
+    CHK(launch_mse_loss(r.pred_c, target, h->scalars, r.dpred_c, B, T, T, D, h->outp, loss_scale, s));
+    if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, h->scalars, sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (Kc > Mr) {
+      HIPCHK(hipMemsetAsync(r.dpred_c + (size_t)Mr * h->outp, 0, (size_t)(Kc - Mr) * h->outp * 2, s));
+      HIPCHK(hipMemsetAsync(r.xf16_c + (size_t)Mr * cr.dp, 0, (size_t)(Kc - Mr) * cr.dp * 2, s));
+    }
+    {
+      hipStream_t w = side_of(h, s);
+      if (w != s) stream_after(h, s, w);
+      CHK(wgrad(h, r.xf16_c, cr.dp, d, r.dpred_c, h->outp, D, Kc, G(h, h->head.w), D, w));
+    }
+    CHK(launch_colsum_bf16(r.dpred_c, h->outp, G(h, h->head_b), Mr, h->outp, D, s));
+    {
+      GemmParams g = gp(r.dpred_c, h->outp, h->head.s, h->head.lds, Mr, d, h->outp);
+      with_skinny(h, g);
+      g.ep.out0 = r.dx_c; g.ep.ldo0 = d; g.ep.out1 = r.dx16_c; g.ep.ldo1 = cr.dp;
+      CHK(launch_gemm_nt(EPI_F32_BF16, g, s));
+    }
+  } else {
+    CHK(head_forward(h, B, h->pred, s));
+    // loss + dL/dpred
+    CHK(launch_mse_loss(h->pred, target, h->scalars, h->dpred, B, cr.n, T, D, h->outp, loss_scale, s));
+    if (loss_out) HIPCHK(hipMemcpyAsync(loss_out, h->scalars, sizeof(float), hipMemcpyDeviceToDevice, s));
+    // head backward
+    {
+      hipStream_t w = side_of(h, s);
+      if (w != s) stream_after(h, s, w);
+      CHK(wgrad(h, h->xf16, cr.dp, d, h->dpred, h->outp, D, Mc, G(h, h->head.w), D, w));
+    }
+    CHK(launch_colsum_bf16(h->dpred, h->outp, G(h, h->head_b), Mc, h->outp, D, s));
+    {
+      GemmParams g = gp(h->dpred, h->outp, h->head.s, h->head.lds, Mc, d, h->outp);
+      g.ep.out0 = h->dx; g.ep.ldo0 = d; g.ep.out1 = h->dx16; g.ep.ldo1 = cr.dp;
+      CHK(launch_gemm_nt(EPI_F32_BF16, g, s));
+    }
   }
   // Gradient buckets are contiguous arena ranges reported in the order they become final:
   // head, cross layers L-1..0, audio stack, motion stack (fact_set_grad_callback).
@@ -1303,7 +1598,8 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   CHK(notify_grads(h, s));  // head
   bf16_t* g16 = h->dx16;  // bf16 gradient at the current layer boundary (re-pointed by every layer)
   for (int l = cr.L - 1; l >= 0; --l) {
-    CHK(layer_backward(h, cr, l, B, h->dx, g16, s, h->bw[0]));
+    if (sr && l == cr.L - 1) CHK(layer_backward_sr(h, cr, l, B, T, h->dx, g16, s, h->bw[0]));
+    else CHK(layer_backward(h, cr, l, B, h->dx, g16, s, h->bw[0]));
     // layer l+1's optimizer-only batch was released inside the call above: its bucket is complete now
     if (l < cr.L - 1) CHK(notify_grads(h, s));
   }

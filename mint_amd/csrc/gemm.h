@@ -55,6 +55,12 @@ struct GemmParams {
   // stream: launches that may run concurrently must not share it.
   float* sk_slab;
   unsigned* sk_cnt;
+  // Skinny-M path (optional): a ZERO-FILLED fp32 accumulator of >= M * round4(N) floats.  When present and
+  // M <= 512 the GEMM runs as split-K 128x128 tiles with fp32 atomics into it (a 320-row GEMM has only 21
+  // N = 800 tiles: the K loop is cut so that ~256 workgroups share it), followed by one element-wise kernel that
+  // applies the fused epilogue and returns the accumulator to zero.  One stream at a time.
+  float* skinny_acc;
+  size_t skinny_floats;
   EpiParams ep;
 };
 constexpr size_t kSplitKSlabBytes = (size_t)256 * 288 * 256 * 4;  // 256 workgroups x the largest tile, fp32
@@ -89,6 +95,9 @@ struct TnGroup {
 // then occupies only ~tiles/parts CUs, which leaves room for the CU-exclusive kernels of another stream.
 int launch_big_tn_group(TnGroup g, hipStream_t stream, int parts = 1);
 void gemm_set_tn_cfg(int v);  // 0 = 160x256 tiles (default), 1 = 160x384 tiles
+
+// skinny-M epilogue pass (gemm_big.hip): out = epilogue(acc[M][ldacc]), acc <- 0
+int launch_skinny_epilogue(int epi, float* acc, int ldacc, const GemmParams& p, hipStream_t stream);
 
 // Launchers. Return 0 on success, negative on invalid arguments.
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);

@@ -1007,6 +1007,30 @@ int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t s) {
   int rc = check_common(p, epi);
   if (rc) return rc;
   if (p.K & 7) return -6;
+  // Skinny-M path (GemmParams::skinny_acc): few row tiles -> cut K so that ~256 workgroups share the GEMM
+  if (p.skinny_acc && p.M <= 512 && p.splitk == 1 && !p.force_generic && !(p.K & 31) && g_nt_variant == 0 &&
+      (epi == EPI_BF16 || epi == EPI_F32_BIAS || epi == EPI_F32_BIAS_RESID || epi == EPI_BIAS_GELU ||
+       epi == EPI_GELU_BWD || epi == EPI_HEADS || epi == EPI_F32_BF16)) {
+    const int ldacc = (p.N + 3) & ~3;
+    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128), ktiles = (p.K + 63) / 64;
+    int sk = 256 / tiles;
+    if (sk > ktiles / 2) sk = ktiles / 2;
+    if (sk >= 2 && (size_t)p.M * ldacc <= p.skinny_floats) {
+      GemmParams q = p;
+      q.splitk = sk;
+      q.skinny_acc = nullptr;
+      q.ep.out0 = p.skinny_acc;
+      q.ep.ldo0 = ldacc;
+      q.ep.alpha = 1.0f;
+      rc = launch_nt_t<EPI_ATOMIC_F32>(q, s);
+      if (rc) return rc;
+      GemmParams e = p;
+      if (epi == EPI_HEADS) {
+        if (p.M >= 65536 || p.N >= 65536) return -8;
+      }
+      return launch_skinny_epilogue(epi, p.skinny_acc, ldacc, e, s);
+    }
+  }
   switch (epi) {
     case EPI_BF16: return launch_nt_t<EPI_BF16>(p, s);
     case EPI_F32_BIAS: return launch_nt_t<EPI_F32_BIAS>(p, s);

@@ -917,6 +917,21 @@ __global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
   }
 }
 
+// Skinny-M GEMMs (gemm.h GemmParams::skinny_acc): element-wise epilogue over the fp32 accumulator the split-K
+// atomics filled; every element is read once, handed to the fused epilogue and written back as zero.
+template <int EPI>
+__global__ __launch_bounds__(256) void skinny_epilogue_kernel(float* __restrict__ acc, int ldacc, const GemmParams p) {
+  const int c4 = (p.N + 3) >> 2;
+  const int total = p.M * c4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int row = i / c4, col0 = (i - row * c4) * 4;
+    float4* a = reinterpret_cast<float4*>(acc + (size_t)row * ldacc + col0);
+    const float4 v = *a;
+    *a = make_float4(0.f, 0.f, 0.f, 0.f);
+    direct_store<EPI>(p.ep, p.M, p.N, row, col0, f32x4{v.x, v.y, v.z, v.w});
+  }
+}
+
 template <typename K>
 int allow_lds(K kernel, int bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -994,6 +1009,23 @@ int launch_big_nt(int cfg, int epi, const GemmParams& p_in, hipStream_t s) {
     case EPI_GELU_BWD: return launch_big_nt_epi<EPI_GELU_BWD>(cfg, p, s);
     case EPI_HEADS: return launch_big_nt_epi<EPI_HEADS>(cfg, p, s);
     case EPI_F32_BF16: return launch_big_nt_epi<EPI_F32_BF16>(cfg, p, s);
+  }
+  return -7;
+}
+
+int launch_skinny_epilogue(int epi, float* acc, int ldacc, const GemmParams& p_in, hipStream_t s) {
+  GemmParams p = p_in;
+  const int total = p.M * ((p.N + 3) >> 2);
+  const dim3 grid((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), block(256);
+  switch (epi) {
+    case EPI_BF16: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_BF16>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_F32_BIAS: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_F32_BIAS>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_F32_BIAS_RESID:
+      hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_F32_BIAS_RESID>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_BIAS_GELU>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_GELU_BWD: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_GELU_BWD>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_HEADS: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_HEADS>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_F32_BF16: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_F32_BF16>, grid, block, 0, s, acc, ldacc, p); return 0;
   }
   return -7;
 }

@@ -118,6 +118,12 @@ int launch_concat_seq(const float* a, const float* b, int B, int na, int nb, int
 // split the cross-modal gradient (B, na+nb, C) into the two encoder gradients (f32 + bf16 copies)
 int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, bf16_t* da16,
                       float* db, bf16_t* db16, int ld16, hipStream_t s);
+// Supervised-rows shortcut (last cross-modal layer): rows (b, t < T) of (B, n, .) tensors <-> compact (B*T, .):
+//   gather : xc f32 [B*T][C] <- x f32 [B*n][C];  ac bf16 [B*T][ld16] <- a bf16 [B*n][ld16]  (either pair may be null)
+//   scatter: dx f32 [B*n][C] <- dxc f32 [B*T][C] on rows t < T, zero elsewhere (all of dx is written)
+int launch_gather_rows(const float* x, const bf16_t* a, int B, int n, int T, int C, int ld16, float* xc, bf16_t* ac,
+                       hipStream_t s);
+int launch_scatter_rows_zero(const float* dxc, int B, int n, int T, int C, float* dx, hipStream_t s);
 // out[i] += sum_z slabs[z*stride + i], i < n (split-K partials -> gradient); stride % 4 == 0
 int launch_slab_reduce(const float* slabs, size_t stride, int nslab, float* out, size_t n, hipStream_t s);
 // sum of squares of a flat f32 buffer -> out[0] (atomicAdd), and flat scale

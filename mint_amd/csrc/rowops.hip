@@ -708,6 +708,35 @@ __global__ void concat_seq_kernel(const float4* __restrict__ a, const float4* __
   }
 }
 
+// Supervised-rows shortcut of the last cross-modal layer (engine.hip): rows (b, t < T) of a (B, n, .) tensor
+// <-> a compact (B*T, .) tensor.
+//   gather : xc f32 [B*T][C] = x[(b*n + t)][C], ac bf16 [B*T][ld16] = a[(b*n + t)][ld16 ...]   (either may be null)
+__global__ void gather_rows_kernel(const float4* __restrict__ x, const bf16x4* __restrict__ a, int B, int n, int T,
+                                   int C4, int ld4, float4* __restrict__ xc, bf16x4* __restrict__ ac) {
+  const size_t total = (size_t)B * T * C4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t row = i / C4;
+    const int c = (int)(i - row * C4);
+    const int b = (int)(row / T), t = (int)(row - (size_t)b * T);
+    const size_t src = (size_t)b * n + t;
+    if (x) xc[row * C4 + c] = x[src * C4 + c];
+    if (a) ac[row * ld4 + c] = a[src * ld4 + c];
+  }
+}
+//   scatter: dx f32 [B*n][C] = dxc[(b*T + t)] on rows t < T, 0 elsewhere (every row of dx is written)
+__global__ void scatter_rows_zero_kernel(const float4* __restrict__ dxc, int B, int n, int T, int C4,
+                                         float4* __restrict__ dx) {
+  const size_t total = (size_t)B * n * C4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const size_t row = i / C4;
+    const int c = (int)(i - row * C4);
+    const int b = (int)(row / n), t = (int)(row - (size_t)b * n);
+    dx[i] = (t < T) ? dxc[((size_t)b * T + t) * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 __global__ void split_grad_kernel(const float4* __restrict__ dx, int B, int na, int nb, int C4, int ld4,
                                   float4* __restrict__ da, bf16x4* __restrict__ da16,
                                   float4* __restrict__ db, bf16x4* __restrict__ db16) {
@@ -953,6 +982,23 @@ int launch_concat_seq(const float* a, const float* b, int B, int na, int nb, int
   const size_t total = (size_t)B * (na + nb) * (C >> 2);
   hipLaunchKernelGGL(concat_seq_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)a,
                      (const float4*)b, B, na, nb, C >> 2, (float4*)out);
+  return 0;
+}
+
+int launch_gather_rows(const float* x, const bf16_t* a, int B, int n, int T, int C, int ld16, float* xc, bf16_t* ac,
+                       hipStream_t s) {
+  if ((C & 3) || (ld16 & 3) || ld16 < C || T > n) return -1;
+  const size_t total = (size_t)B * T * (C >> 2);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)x,
+                     (const bf16x4*)a, B, n, T, C >> 2, ld16 >> 2, (float4*)xc, (bf16x4*)ac);
+  return 0;
+}
+
+int launch_scatter_rows_zero(const float* dxc, int B, int n, int T, int C, float* dx, hipStream_t s) {
+  if ((C & 3) || T > n) return -1;
+  const size_t total = (size_t)B * n * (C >> 2);
+  hipLaunchKernelGGL(scatter_rows_zero_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)dxc, B, n, T,
+                     C >> 2, (float4*)dx);
   return 0;
 }
 

@@ -574,3 +574,40 @@ def test_ragged_lengths_second_step_grads():
         r = ref_grads[name]
         if float(r.norm()) > 1e-12:
             assert cos(g, r) > 0.995, "%s cos %.5f" % (name, cos(g, r))
+
+
+@pytest.mark.parametrize("cfg_name,B,T", [("tiny", 4, 8), ("tiny", 3, 5), ("fact_v5", 16, 20)])
+def test_supervised_rows_shortcut_matches_full_last_layer(cfg_name, B, T):
+    """The training step runs the LAST cross-modal layer (attention queries, to_out, LayerNorm 2, MLP, head and their
+    dgrads / wgrads) only on the B*T rows the loss reads (fact_model.py:143-148; engine option sr_rows, default on).
+    Loss and every gradient tensor must equal the full-row computation up to bf16 / summation-order rounding:
+    loss rel <= 1e-4, per-tensor rel-Frobenius <= 2e-2 and cosine >= 0.9995; B*T = 15 exercises the zero-padded
+    compact rows (wgrad contraction padded to 64) and, at fact_v5 B=16, the grouped big-tile wgrad launches."""
+    cfg = O.TINY_CFG if cfg_name == "tiny" else O.FACT_V5_CFG
+    model = model_builder.build(make_config(cfg), True)
+    batch = O.synthetic_batch(cfg, B, T, seed=3, dtype=torch.float32)
+    gb = gpu_batch(batch)
+    model.build(max(B, 4), 225, 35)
+    _randomize(model, seed=5)
+    res = {}
+    for sr in (1, 0, 1):  # on, off, on again (second pass through dirtied compact / dO scratch)
+        model.set_option("sr_rows", sr)
+        model.grad_arena.zero_()
+        loss = float(model.forward_backward(gb, gb["target"]))
+        assert torch.isfinite(model.grad_arena).all()
+        res[sr] = (loss, [g.detach().clone() for g in model.gradients])
+    model.set_option("sr_rows", 1)
+    (l1, g1), (l0, g0) = res[1], res[0]
+    assert abs(l1 - l0) / abs(l0) < 1e-4, (l1, l0)
+    worst = (1.0, "", 0.0)
+    for name, a, b in zip(model.variable_names, g1, g0):
+        if float(b.norm()) < 1e-12:
+            assert float(a.norm()) < 1e-6, name
+            continue
+        c, r = cos(a, b), rel(a, b)
+        worst = min(worst, (c, name, r))
+        assert c > 0.9995 and r < 2e-2, "%s cos %.6f rel %.4f" % (name, c, r)
+    print("supervised-rows vs full rows: worst cosine %.6f (%s, rel %.4f)" % worst)
+    # full forward (all rows returned) is untouched by the option
+    out = model(gb)
+    assert out.shape[1] == cfg["motion"]["seq_len"] + cfg["audio"]["seq_len"]
