@@ -61,8 +61,12 @@ def main():
     f = lambda v, w, p: ("%*.*f" % (w, p, v)) if v is not None else " " * (w - 1) + "-"
     lines = ["%-66s %6s %10s %7s %9s %7s %9s %9s" % ("kernel", "calls", "cycles", "mfma%", "conflict%", "wait%",
                                                    "read_MB", "write_MB")]
+    def short(n):
+        for a in ("void (anonymous namespace)::", "(anonymous namespace)::", "_ZN12_GLOBAL__N_1"):
+            n = n.replace(a, "")
+        return n.replace("BigCfg", "Cfg").replace(", ", ",")
     for r in rows[:48]:
-        lines.append("%-66s %6d %s %s %s %s %s %s" % (r["name"][:66], r["calls"], f(r["cycles"], 10, 0),
+        lines.append("%-66s %6d %s %s %s %s %s %s" % (short(r["name"])[:66], r["calls"], f(r["cycles"], 10, 0),
                                                      f(r["mfma"], 7, 1), f(r["conflict"], 9, 2), f(r["wait"], 7, 1),
                                                      f(r["rd_mb"], 9, 1), f(r["wr_mb"], 9, 1)))
     text = "\n".join(lines)
