@@ -652,6 +652,7 @@ int adam_bucket(FactHandle* h, int b, hipStream_t s) {
 }
 
 int g_op_ln_ws = 0;            // bench knob (fact_debug_ln_bwd)
+int g_op_tn_parts = 1;         // bench knob (fact_debug_gemm_tn_cfg): launches per group of fact_op_gemm_tn_group
 int g_force_generic_gemm = 0;  // test knob (fact_debug_force_generic_gemm)
 
 GemmParams gp(const bf16_t* A, int lda, const bf16_t* B, int ldb, int M, int N, int K) {
@@ -1888,11 +1889,12 @@ int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const voi
     q.A = (const bf16_t*)A[i]; q.lda = lda[i]; q.B = (const bf16_t*)B[i]; q.ldb = ldb[i];
     q.out = out[i]; q.ldo = ldo[i]; q.M = Mo[i]; q.N = No[i]; q.trans_out = trans[i];
   }
-  CHK(launch_big_tn_group(g, (hipStream_t)stream));
+  CHK(launch_big_tn_group(g, (hipStream_t)stream, g_op_tn_parts));
   return 0;
 }
-int fact_debug_gemm_tn_cfg(int v) {
-  gemm_set_tn_cfg(v);
+int fact_debug_gemm_tn_cfg(int v) {  // low byte: main loop (0 staggered, 1 / 2 fragment prefetch); bits 8..: launches per group of the op
+  gemm_set_tn_cfg(v & 0xff);
+  g_op_tn_parts = (v >> 8) > 0 ? (v >> 8) : 1;
   return 0;
 }
 int fact_debug_gemm_splitk_max(int v) {

@@ -66,7 +66,7 @@ struct BigCfg {
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
   static constexpr int LPS_LO = NPIECE / 8, EXTRA = NPIECE % 8;  // waves < EXTRA issue one more piece
   static_assert(WGM * WGN == 8, "8 waves");
-  static_assert(NSTAGE == 3 || NSTAGE == 4, "ring depth");
+  static_assert(NSTAGE >= 3 && NSTAGE <= 6, "ring depth");
   static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS");
 };
 
@@ -135,7 +135,7 @@ struct TnImg {
 };
 
 template <class C, int SO, int PAIR, int J>
-DEVINL void tn_reads_b(const unsigned (&tb)[C::NR][2], bf16x4 (&blo)[C::NR], bf16x4 (&bhi)[C::NR]) {
+DEVINL void tn_reads_b(const unsigned (&tb)[C::NR][(C::NSTAGE + 1) / 2], bf16x4 (&blo)[C::NR], bf16x4 (&bhi)[C::NR]) {
   if constexpr (J < C::NR) {
     constexpr int DH = TnImg<C::BN>::template dhh_of<C::WGN, C::NR>(J);
     blo[J] = tr_read<SO>(tb[J][PAIR]);
@@ -144,7 +144,7 @@ DEVINL void tn_reads_b(const unsigned (&tb)[C::NR][2], bf16x4 (&blo)[C::NR], bf1
   }
 }
 template <class C, int SO, int PAIR, int I>
-DEVINL void tn_reads_a(const unsigned (&ta)[C::MR][2], bf16x4 (&alo)[C::MR], bf16x4 (&ahi)[C::MR]) {
+DEVINL void tn_reads_a(const unsigned (&ta)[C::MR][(C::NSTAGE + 1) / 2], bf16x4 (&alo)[C::MR], bf16x4 (&ahi)[C::MR]) {
   if constexpr (I < C::MR) {
     constexpr int DH = TnImg<C::BM>::template dhh_of<C::WGM, C::MR>(I);
     alo[I] = tr_read<SO>(ta[I][PAIR]);
@@ -154,7 +154,7 @@ DEVINL void tn_reads_a(const unsigned (&ta)[C::MR][2], bf16x4 (&alo)[C::MR], bf1
 }
 // transpose read number R (0 .. 2*(NR+MR)-1) of a TN stage: B units first, then A units; even R = hh 0, odd = hh 1
 template <class C, int SO, int PAIR, int R>
-DEVINL void tn_read_one(const unsigned (&ta)[C::MR][2], const unsigned (&tb)[C::NR][2], bf16x4 (&alo)[C::MR],
+DEVINL void tn_read_one(const unsigned (&ta)[C::MR][(C::NSTAGE + 1) / 2], const unsigned (&tb)[C::NR][(C::NSTAGE + 1) / 2], bf16x4 (&alo)[C::MR],
                         bf16x4 (&ahi)[C::MR], bf16x4 (&blo)[C::NR], bf16x4 (&bhi)[C::NR]) {
   if constexpr (R < 2 * C::NR) {
     constexpr int J = R / 2;
@@ -174,7 +174,7 @@ DEVINL void mfma16_asm(f32x4& c, bf16x8 a, bf16x8 b) {
 // MFMA number X of a step (row-major over the MR x NR tile) followed by transpose read number X of the next stage
 template <class C, bool SWAP, int SO, int PAIR, int X, int ABL = 0>
 DEVINL void tn_mfma_read_chain(f32x4 (&acc)[C::MR][C::NR], const bf16x8 (&af)[C::MR], const bf16x8 (&bfr)[C::NR],
-                               const unsigned (&ta)[C::MR][2], const unsigned (&tb)[C::NR][2], bf16x4 (&alo)[C::MR],
+                               const unsigned (&ta)[C::MR][(C::NSTAGE + 1) / 2], const unsigned (&tb)[C::NR][(C::NSTAGE + 1) / 2], bf16x4 (&alo)[C::MR],
                                bf16x4 (&ahi)[C::MR], bf16x4 (&blo)[C::NR], bf16x4 (&bhi)[C::NR]) {
   if constexpr (X < C::MR * C::NR) {
     constexpr int I = X / C::NR, J = X % C::NR;
@@ -189,7 +189,7 @@ DEVINL void tn_mfma_read_chain(f32x4 (&acc)[C::MR][C::NR], const bf16x8 (&af)[C:
 
 // The 2 * (MR + NR) transpose reads of one TN stage: B units first (the multiply needs them for every MFMA).
 template <class C, int SO, int PAIR>
-DEVINL void tn_reads(const unsigned (&ta)[C::MR][2], const unsigned (&tb)[C::NR][2], bf16x4 (&alo)[C::MR],
+DEVINL void tn_reads(const unsigned (&ta)[C::MR][(C::NSTAGE + 1) / 2], const unsigned (&tb)[C::NR][(C::NSTAGE + 1) / 2], bf16x4 (&alo)[C::MR],
                      bf16x4 (&ahi)[C::MR], bf16x4 (&blo)[C::NR], bf16x4 (&bhi)[C::NR]) {
   tn_reads_b<C, SO, PAIR, 0>(tb, blo, bhi);
   tn_reads_a<C, SO, PAIR, 0>(ta, alo, ahi);
@@ -244,7 +244,7 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
 
   // loop-invariant fragment addresses
   unsigned a_nt[NST], b_nt[NST];          // NT: per ring slot, + i * 1024 immediates
-  unsigned ta[MR][2], tb[NR][2];          // TN: per unit and slot pair {0,1} / {2,3}, + immediates
+  unsigned ta[MR][(NST + 1) / 2], tb[NR][(NST + 1) / 2];  // TN: per unit and slot pair {0,1} / {2,3}, + immediates
   if constexpr (!TN) {
     const int r = lane & 15, chunk = lane >> 4;
     const unsigned lanepart = (unsigned)(r * 64 + ((chunk ^ ring_g(r)) << 4));
@@ -354,9 +354,12 @@ DEVINL void tn_mainloop_pf(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
                            const unsigned (&sadv)[C::LPS_LO + 1], const unsigned (&voff)[C::LPS_LO + 1],
                            const int (&dst)[C::LPS_LO + 1], int nk, int wave, int wm, int wn, int lane,
                            f32x4 (&acc)[C::MR][C::NR]) {
-  constexpr int MR = C::MR, NR = C::NR, STAGE = C::STAGE_BYTES;
+  constexpr int MR = C::MR, NR = C::NR, STAGE = C::STAGE_BYTES, NS = C::NSTAGE, NPAIR = (NS + 1) / 2;
   constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
-  static_assert(C::NSTAGE == 4, "loop is unrolled over 4 ring slots");
+  // ring of NS slots: stage k+NS-1 is issued at step k (into the slot stage k-1 used); the wait at the top of step
+  // k leaves the NS-3 youngest stages in flight (NS = 4: one, the round-2b loop; NS = 6: three - the deeper ring
+  // rides out the longer L2 / fabric latency the kernel sees when it shares the chip with the dgrad chain)
+  static_assert(NS >= 4 && NS <= 6, "ring depth of the prefetch loop");
   const bool extra = EXTRA && wave < EXTRA;
   auto stage = [&](auto slot_c, bool more) {
     constexpr int SLOT = decltype(slot_c)::value;
@@ -367,31 +370,31 @@ DEVINL void tn_mainloop_pf(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
 #pragma unroll
     for (int i = 0; i < LPS_LO + 1; ++i) sptr[i] += more ? sadv[i] : 0u;
   };
-  auto wait1 = [&]() {  // at most 1 later stage of this wave stays in flight
-    if (extra) wait_vmcnt<LPS_LO + 1>();
-    else wait_vmcnt<LPS_LO>();
+  auto wait_top = [&]() {  // at most NS - 3 later stages of this wave stay in flight
+    if (extra) wait_vmcnt<(NS - 3) * (LPS_LO + 1)>();
+    else wait_vmcnt<(NS - 3) * LPS_LO>();
   };
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  unsigned ta[MR][2], tb[NR][2];
+  unsigned ta[MR][NPAIR], tb[NR][NPAIR];  // per slot pair {2p, 2p+1}: + (slot & 1) * STAGE as an immediate
   {
     const unsigned l0 = lds_addr(smem);
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
       unsigned off, dh;
       TnImg<C::BM>::frag_off(TnImg<C::BM>::template unit_of<C::WGM, MR>(wm, i), lane, off, dh);
-      ta[i][0] = l0 + off;
-      ta[i][1] = l0 + off + 2 * STAGE;
+#pragma unroll
+      for (int pr = 0; pr < NPAIR; ++pr) ta[i][pr] = l0 + off + 2 * pr * STAGE;
     }
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       unsigned off, dh;
       TnImg<C::BN>::frag_off(TnImg<C::BN>::template unit_of<C::WGN, NR>(wn, j), lane, off, dh);
-      tb[j][0] = l0 + C::A_BYTES + off;
-      tb[j][1] = l0 + C::A_BYTES + off + 2 * STAGE;
+#pragma unroll
+      for (int pr = 0; pr < NPAIR; ++pr) tb[j][pr] = l0 + C::A_BYTES + off + 2 * pr * STAGE;
     }
   }
   // two fragment register sets
@@ -400,37 +403,41 @@ DEVINL void tn_mainloop_pf(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
   stage(SlotC<0>{}, 1 < nk);
   stage(SlotC<1>{}, 2 < nk);
   stage(SlotC<2>{}, 3 < nk);
-  if (extra) wait_vmcnt<2 * (LPS_LO + 1)>();
-  else wait_vmcnt<2 * LPS_LO>();
+  if constexpr (NS >= 5) stage(SlotC<3>{}, 4 < nk);
+  if constexpr (NS >= 6) stage(SlotC<4>{}, 5 < nk);
+  if (extra) wait_vmcnt<(NS - 2) * (LPS_LO + 1)>();
+  else wait_vmcnt<(NS - 2) * LPS_LO>();
   __builtin_amdgcn_s_barrier();  // stage 0 landed
   tn_reads<C, 0, 0>(ta, tb, alo0, ahi0, blo0, bhi0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
-  auto body = [&](auto slot_c, int kt) {
+  // `par` = parity of the step (which fragment register set holds stage kt); the ring slot is compile time
+  auto body = [&](auto slot_c, auto par_c, int kt) {
     constexpr int SLOT = decltype(slot_c)::value;     // ring slot of stage kt
-    constexpr int NS = (SLOT + 1) & 3;                // ring slot of stage kt + 1
-    constexpr int SO = (NS & 1) * STAGE, PAIR = NS / 2;
-    if constexpr (ABL != 1) wait1();
+    constexpr int PAR = decltype(par_c)::value;
+    constexpr int NSL = (SLOT + 1) % NS;              // ring slot of stage kt + 1
+    constexpr int SO = (NSL & 1) * STAGE, PAIR = NSL / 2;
+    if constexpr (ABL != 1) wait_top();
     __builtin_amdgcn_s_barrier();
-    if constexpr (ABL != 1) stage(SlotC<(SLOT + 3) & 3>{}, kt + 4 < nk);  // ABL 1: no DMA in the loop
+    if constexpr (ABL != 1) stage(SlotC<(SLOT + NS - 1) % NS>{}, kt + NS < nk);  // ABL 1: no DMA in the loop
     if constexpr (!FINE) {
-      if constexpr ((SLOT & 1) == 0) tn_reads<C, SO, PAIR>(ta, tb, alo1, ahi1, blo1, bhi1);
+      if constexpr (PAR == 0) tn_reads<C, SO, PAIR>(ta, tb, alo1, ahi1, blo1, bhi1);
       else tn_reads<C, SO, PAIR>(ta, tb, alo0, ahi0, blo0, bhi0);
     }
     bf16x8 af[MR], bfr[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j)
-      bfr[j] = (SLOT & 1) ? __builtin_shufflevector(blo1[j], bhi1[j], 0, 1, 2, 3, 4, 5, 6, 7)
-                          : __builtin_shufflevector(blo0[j], bhi0[j], 0, 1, 2, 3, 4, 5, 6, 7);
+      bfr[j] = PAR ? __builtin_shufflevector(blo1[j], bhi1[j], 0, 1, 2, 3, 4, 5, 6, 7)
+                   : __builtin_shufflevector(blo0[j], bhi0[j], 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
     for (int i = 0; i < MR; ++i)
-      af[i] = (SLOT & 1) ? __builtin_shufflevector(alo1[i], ahi1[i], 0, 1, 2, 3, 4, 5, 6, 7)
-                         : __builtin_shufflevector(alo0[i], ahi0[i], 0, 1, 2, 3, 4, 5, 6, 7);
+      af[i] = PAR ? __builtin_shufflevector(alo1[i], ahi1[i], 0, 1, 2, 3, 4, 5, 6, 7)
+                  : __builtin_shufflevector(alo0[i], ahi0[i], 0, 1, 2, 3, 4, 5, 6, 7);
     if constexpr (FINE) {
       // one transpose read of stage k+1 behind every MFMA of stage k (both as asm: program order is issue order)
       static_assert(2 * (MR + NR) <= MR * NR, "a read slot per MFMA");
-      if constexpr ((SLOT & 1) == 0)
+      if constexpr (PAR == 0)
         tn_mfma_read_chain<C, SWAP, SO, PAIR, 0, ABL>(acc, af, bfr, ta, tb, alo1, ahi1, blo1, bhi1);
       else
         tn_mfma_read_chain<C, SWAP, SO, PAIR, 0, ABL>(acc, af, bfr, ta, tb, alo0, ahi0, blo0, bhi0);
@@ -448,11 +455,23 @@ DEVINL void tn_mainloop_pf(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
   };
-  for (int kt = 0; kt < nk; kt += 4) {
-    body(SlotC<0>{}, kt);
-    if (kt + 1 < nk) body(SlotC<1>{}, kt + 1);
-    if (kt + 2 < nk) body(SlotC<2>{}, kt + 2);
-    if (kt + 3 < nk) body(SlotC<3>{}, kt + 3);
+  // unrolled over lcm(NS, 2) steps so that both the ring slot and the fragment-set parity are compile time
+  constexpr int UNR = (NS % 2 == 0) ? NS : 2 * NS;
+  for (int kt = 0; kt < nk; kt += UNR) {
+    body(SlotC<0>{}, SlotC<0>{}, kt);
+    if (kt + 1 < nk) body(SlotC<1 % NS>{}, SlotC<1>{}, kt + 1);
+    if (kt + 2 < nk) body(SlotC<2 % NS>{}, SlotC<0>{}, kt + 2);
+    if (kt + 3 < nk) body(SlotC<3 % NS>{}, SlotC<1>{}, kt + 3);
+    if constexpr (UNR > 4) {
+      if (kt + 4 < nk) body(SlotC<4 % NS>{}, SlotC<0>{}, kt + 4);
+      if (kt + 5 < nk) body(SlotC<5 % NS>{}, SlotC<1>{}, kt + 5);
+    }
+    if constexpr (UNR > 6) {
+      if (kt + 6 < nk) body(SlotC<6 % NS>{}, SlotC<0>{}, kt + 6);
+      if (kt + 7 < nk) body(SlotC<7 % NS>{}, SlotC<1>{}, kt + 7);
+      if (kt + 8 < nk) body(SlotC<8 % NS>{}, SlotC<0>{}, kt + 8);
+      if (kt + 9 < nk) body(SlotC<9 % NS>{}, SlotC<1>{}, kt + 9);
+    }
   }
   wait_vmcnt<0>();  // run-ahead stages past the end of K
   // asm MFMAs: the accumulators are read by the compiler's epilogue code - cover the XDL write-back latency
@@ -961,6 +980,7 @@ using Cfg288x256 = BigCfg<2, 9, 4, 4>;
 using Cfg256x256 = BigCfg<2, 8, 4, 4>;
 using Cfg256x160 = BigCfg<4, 4, 2, 5>;
 using Cfg160x256 = BigCfg<2, 5, 4, 4>;
+using Cfg160x256r6 = BigCfg<2, 5, 4, 4, 6>;  // 6-slot LDS-DMA ring (160 KiB) for the fragment-prefetch TN loop (tn_loop = 6)
 // 2 workgroups per CU (3-deep ring, 72 KiB; 64x64 wave tile -> <= 128 VGPRs): the epilogue of one workgroup (bias /
 // GELU math, staging, 35-70 MB of stores for the K = 800 GEMMs) runs under the main loop of the other
 using Cfg256x128 = BigCfg<4, 4, 2, 4, 3, 2>;
@@ -1066,6 +1086,7 @@ void gemm_set_tn_cfg(int v) { g_tn_cfg = v; }
 int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
   if (g_tn_cfg == 1) return launch_big_tn_group_t<Cfg160x256, 1>(g, s, parts);
   if (g_tn_cfg == 2) return launch_big_tn_group_t<Cfg160x256, 2>(g, s, parts);
+  if (g_tn_cfg == 6) return launch_big_tn_group_t<Cfg160x256r6, 2>(g, s, parts);  // interleaved loop, 6-slot ring
 #ifdef BIG_ABLATION
   if (g_tn_cfg == 3) return launch_big_tn_group_t<Cfg160x256, 3>(g, s, parts);  // interleaved loop without DMA
   if (g_tn_cfg == 4) return launch_big_tn_group_t<Cfg160x256, 4>(g, s, parts);  // ... without MFMAs

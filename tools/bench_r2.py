@@ -115,7 +115,7 @@ def wgrad_layer(K, d=800, ff=3072):
     t_old, t_new = time_us(old), time_us(new)
     line = ""
     for cfg in [int(x) for x in os.environ.get('TN_LOOPS', '1,2,0').split(',')]:
-        lib.fact_debug_gemm_tn_cfg(cfg)
+        lib.fact_debug_gemm_tn_cfg(cfg + 256 * int(os.environ.get('TN_PARTS', '1')))
         for o in outs_new:
             o.zero_()
         new()
