@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--fuse-optimizer", type=int, default=1, help="0 = Adam as a separate pass after backward (A/B knob)")
     ap.add_argument("--mode", choices=["train", "ar", "scaled"], default="train")
     ap.add_argument("--profile-steps", type=int, default=4, help="extra steps for the in-step kernel table")
+    ap.add_argument("--grad-buckets", choices=["bf16", "fp32"], default="bf16",
+                    help="N > 1: dtype of the all-reduced gradient buckets (bf16: 240.8 MB per step, fp32: 481.6 MB)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="engine option for A/B runs (fact_set_option), e.g. --opt wgrad_parts=1")
     return ap.parse_args()
@@ -301,7 +303,8 @@ def main():
         def __next__(self):
             return batch
 
-    trainer = SingleTaskTrainer(Repeat(), "target", model, optimizer=opt, fuse_optimizer=bool(args.fuse_optimizer))
+    trainer = SingleTaskTrainer(Repeat(), "target", model, optimizer=opt, fuse_optimizer=bool(args.fuse_optimizer),
+                                bf16_grad_buckets=(world > 1 and args.grad_buckets == "bf16"))
     it = iter(Repeat())
 
     def sync():
@@ -357,7 +360,9 @@ def main():
             "config": {"workload": "fact_v5_deeper_t10_cm12 train step (BASELINE.json configs[%d])"
                                    % (1 if world == 1 else 2),
                        "global_batch": world * B, "per_gpu_batch": B, "motion_seq": 120, "audio_seq": 240,
-                       "target_frames": TARGET_LEN, "parallelism": "dp%d" % world, "params": 120406977},
+                       "target_frames": TARGET_LEN, "parallelism": "dp%d" % world, "params": 120406977,
+                       "grad_allreduce": ("none (single replica)" if world == 1 else
+                                          "%s buckets on a communication stream, overlapped with backward" % args.grad_buckets)},
             "samples_per_sec": round(frames_per_s / 120, 2),
             # MFMA work actually executed (the supervised-rows shortcut skips ~5 % of the reference step's FLOPs)
             "executed_flop_fraction": round(executed_flop_fraction(), 4),
