@@ -5,7 +5,9 @@ Yields dicts of torch tensors (`motion_input`, `audio_input`, `target`) plus the
 reference (which drops the input_context, trainer.py:102-103).  CPU-side plumbing only; the
 benchmark uses synthetic tensors of the same shapes."""
 import glob as _glob
+import queue as _queue
 import random
+import threading
 
 import numpy as np
 import torch
@@ -23,10 +25,56 @@ def _decode(payload, modalities):
     return out
 
 
+def prefetch(gen, depth=2):
+    """`ds.prefetch(...)` (inputs.py:118-123): a daemon thread runs the producer `gen` (file reads, Example
+    decoding, FACT windowing, collation, pinned host-to-device copies) up to `depth` batches ahead of the consumer,
+    so the next batch is staged while the GPU runs the current step.  Order is preserved, an exception in the producer
+    re-raises in the consumer, and closing / dropping the returned generator stops the thread."""
+    q = _queue.Queue(maxsize=max(1, int(depth)))
+    stop = threading.Event()
+    END, ERR = object(), object()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except _queue.Full:
+                continue
+        return False
+
+    def work():
+        try:
+            for item in gen:
+                if not put(item):
+                    return
+            put(END)
+        except BaseException as e:  # handed to the consumer
+            put((ERR, e))
+
+    t = threading.Thread(target=work, name="mint_amd-input-prefetch", daemon=True)
+    t.start()
+
+    def consume():
+        try:
+            while True:
+                item = q.get()
+                if item is END:
+                    return
+                if isinstance(item, tuple) and len(item) == 2 and item[0] is ERR:
+                    raise item[1]
+                yield item
+        finally:
+            stop.set()
+
+    return consume()
+
+
 def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_training=True, use_tpu=False,
-                 device=None, seed=None):
+                 device=None, seed=None, prefetch_batches=2):
     """Generator of feature dicts (inputs.py:20-123). Training: shuffle(100), repeat forever,
-    drop the remainder; eval: one pass in file order, remainder kept."""
+    drop the remainder; eval: one pass in file order, remainder kept.  `prefetch_batches` > 0 stages that many
+    batches ahead on a background thread (the reference's `ds.prefetch`); 0 = synchronous."""
     batch_size = train_eval_config.batch_size
     files = sorted(_glob.glob(dataset_config.data_files))
     if not files:
@@ -82,4 +130,4 @@ def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_traini
         if batch and not is_training:
             yield collate(batch)
 
-    return batches()
+    return prefetch(batches(), prefetch_batches) if prefetch_batches and prefetch_batches > 0 else batches()

@@ -94,3 +94,119 @@ def test_reference_inputs_util_test_vector():
     p = inputs_util.get_modality_to_param_dict(d)
     assert (p["motion"]["input_length"], p["motion"]["target_length"], p["motion"]["target_shift"]) == (10, 5, 2)
     assert (p["visual"]["input_length"], p["visual"]["target_length"], p["visual"]["target_shift"]) == (20, 10, 4)
+
+
+def test_prefetch_thread_preserves_order_and_propagates_errors():
+    """inputs.prefetch = the reference's ds.prefetch: a background producer thread, same order, errors re-raised in
+    the consumer, producer stopped when the consumer goes away."""
+    import threading
+    import time
+    from mint_amd import inputs
+
+    produced = []
+
+    def gen(n, fail_at=None):
+        for i in range(n):
+            if fail_at is not None and i == fail_at:
+                raise RuntimeError("boom at %d" % i)
+            produced.append(i)
+            yield {"i": i}
+
+    assert [b["i"] for b in inputs.prefetch(gen(20), depth=3)] == list(range(20))
+    # runs ahead of the consumer, but never more than depth (+ the item in hand) batches
+    del produced[:]
+    it = inputs.prefetch(gen(100), depth=2)
+    assert next(it)["i"] == 0
+    time.sleep(0.3)
+    assert 2 <= len(produced) <= 4, produced
+    it.close()  # consumer gone: the producer thread must stop
+    time.sleep(0.3)
+    n = len(produced)
+    time.sleep(0.3)
+    assert len(produced) == n and n < 100
+    assert not any(t.name == "mint_amd-input-prefetch" and t.is_alive() for t in threading.enumerate())
+    # producer exception surfaces in the consumer after the batches before it
+    got = []
+    with pytest.raises(RuntimeError, match="boom at 3"):
+        for b in inputs.prefetch(gen(10, fail_at=3), depth=2):
+            got.append(b["i"])
+    assert got == [0, 1, 2]
+
+
+def _example_classes():
+    """tf.train.Example message classes built with the OFFICIAL protobuf runtime from the published schema
+    (tensorflow/core/example/{feature,example}.proto) - an encoder independent of mint_amd.tfrecord's own writer."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    fd = descriptor_pb2.FileDescriptorProto()
+    fd.name, fd.package, fd.syntax = "tf_example_fixture.proto", "tensorflow", "proto3"
+    T = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name, fields):
+        m = fd.message_type.add()
+        m.name = name
+        for (fname, num, typ, label, type_name, packed) in fields:
+            f = m.field.add()
+            f.name, f.number, f.type, f.label = fname, num, typ, label
+            if type_name:
+                f.type_name = type_name
+            if packed:
+                f.options.packed = True
+        return m
+    msg("BytesList", [("value", 1, T.TYPE_BYTES, T.LABEL_REPEATED, None, False)])
+    msg("FloatList", [("value", 1, T.TYPE_FLOAT, T.LABEL_REPEATED, None, True)])
+    msg("Int64List", [("value", 1, T.TYPE_INT64, T.LABEL_REPEATED, None, True)])
+    feat = msg("Feature", [("bytes_list", 1, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, ".tensorflow.BytesList", False),
+                           ("float_list", 2, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, ".tensorflow.FloatList", False),
+                           ("int64_list", 3, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, ".tensorflow.Int64List", False)])
+    feat.oneof_decl.add().name = "kind"
+    for f in feat.field:
+        f.oneof_index = 0
+    feats = msg("Features", [("feature", 1, T.TYPE_MESSAGE, T.LABEL_REPEATED, ".tensorflow.Features.FeatureEntry", False)])
+    entry = feats.nested_type.add()
+    entry.name = "FeatureEntry"
+    entry.options.map_entry = True
+    for (fname, num, typ, tn) in (("key", 1, T.TYPE_STRING, None), ("value", 2, T.TYPE_MESSAGE, ".tensorflow.Feature")):
+        f = entry.field.add()
+        f.name, f.number, f.type, f.label = fname, num, typ, T.LABEL_OPTIONAL
+        if tn:
+            f.type_name = tn
+    msg("Example", [("features", 1, T.TYPE_MESSAGE, T.LABEL_OPTIONAL, ".tensorflow.Features", False)])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return message_factory.GetMessageClass(pool.FindMessageTypeByName("tensorflow.Example"))
+
+
+def test_reader_parses_examples_encoded_by_the_official_protobuf_runtime(tmp_path):
+    """The TFRecord / tf.train.Example reader against records that were NOT produced by mint_amd's own writer: the
+    Examples are serialised by google.protobuf from the published tf.train.Example schema (packed float / int64 lists,
+    map<string, Feature>), with the feature layout of the reference's tools/preprocessing.py:54-69, and framed per the
+    TFRecord spec (little-endian u64 length, masked crc32c of length and payload)."""
+    pytest.importorskip("google.protobuf")
+    import struct
+    Example = _example_classes()
+    rng = np.random.RandomState(4)
+    recs = []
+    for i in range(3):
+        motion = rng.randn(30 + i, 225).astype(np.float32)
+        audio = rng.randn(40 + i, 35).astype(np.float32)
+        ex = Example()
+        f = ex.features.feature
+        f["motion_name"].bytes_list.value.append(("gBR_sBM_c01_d04_mBR0_ch0%d" % i).encode())
+        f["motion_sequence"].float_list.value.extend(motion.reshape(-1).tolist())
+        f["motion_sequence_shape"].int64_list.value.extend(motion.shape)
+        f["audio_name"].bytes_list.value.append(("mBR%d" % i).encode())
+        f["audio_sequence"].float_list.value.extend(audio.reshape(-1).tolist())
+        f["audio_sequence_shape"].int64_list.value.extend(audio.shape)
+        recs.append((ex.SerializeToString(), motion, audio))
+    path = tmp_path / "official.tfrecord"
+    with open(path, "wb") as fh:
+        for payload, _, _ in recs:
+            hdr = struct.pack("<Q", len(payload))
+            fh.write(hdr + struct.pack("<I", tfrecord._masked(hdr)) + payload + struct.pack("<I", tfrecord._masked(payload)))
+    got = list(tfrecord.read_records(str(path)))
+    assert len(got) == 3
+    for payload, (_, motion, audio) in zip(got, recs):
+        ex = inputs._decode(payload, ["motion", "audio"])
+        assert ex["motion_name"].startswith("gBR_sBM") and ex["audio_name"].startswith("mBR")
+        np.testing.assert_array_equal(ex["motion_sequence"], motion)
+        np.testing.assert_array_equal(ex["audio_sequence"], audio)
