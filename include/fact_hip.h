@@ -63,6 +63,10 @@ typedef struct FactArenas {
 } FactArenas;
 
 int fact_abi_version(void);
+/* Host utility (no GPU work): CRC-32C (Castagnoli) of `n` bytes continuing from `crc` (0 to start) - the checksum of
+ * TFRecord frames (mint/core/inputs.py reads them through tf.data) and of TensorFlow tensor-bundle entries
+ * (trainer.py:168-173 checkpoints); mint_amd/tfrecord.py and tf_checkpoint.py use it for large payloads. */
+unsigned int fact_crc32c(const void* data, size_t n, unsigned int crc);
 const char* fact_last_error(void);
 
 /* Number of floats in each arena (padded, 16-byte aligned tensors) and number of tensors. */

@@ -42,6 +42,7 @@ GRAD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "fact_abi_version": (_i, []),
+    "fact_crc32c": (C.c_uint, [_vp, C.c_size_t, C.c_uint]),
     "fact_last_error": (C.c_char_p, []),
     "fact_arena_size": (_i, [C.POINTER(FactConfig), C.POINTER(_sz), C.POINTER(_i)]),
     "fact_create": (_i, [C.POINTER(FactConfig), _i, _i, C.POINTER(FactArenas), C.POINTER(_vp)]),

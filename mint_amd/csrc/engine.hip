@@ -1282,6 +1282,36 @@ int check_batch(FactHandle* h, int B) {
 extern "C" {
 
 int fact_abi_version(void) { return FACT_ABI_VERSION; }
+
+unsigned int fact_crc32c(const void* data, size_t n, unsigned int crc) {
+  // slicing-by-8, tables built on first use (reflected polynomial 0x82F63B78)
+  static uint32_t T[8][256];
+  static bool ready = false;
+  if (!ready) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      T[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
+    ready = true;
+  }
+  const unsigned char* p = (const unsigned char*)data;
+  uint32_t c = ~crc;
+  while (n >= 8) {
+    uint32_t lo, hi;
+    memcpy(&lo, p, 4);
+    memcpy(&hi, p + 4, 4);
+    lo ^= c;
+    c = T[7][lo & 0xff] ^ T[6][(lo >> 8) & 0xff] ^ T[5][(lo >> 16) & 0xff] ^ T[4][lo >> 24] ^ T[3][hi & 0xff] ^
+        T[2][(hi >> 8) & 0xff] ^ T[1][(hi >> 16) & 0xff] ^ T[0][hi >> 24];
+    p += 8;
+    n -= 8;
+  }
+  while (n--) c = T[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+  return ~c;
+}
 const char* fact_last_error(void) { return g_err.c_str(); }
 
 static void init_geo(FactHandle* h, const FactConfig* cfg) {

@@ -18,11 +18,34 @@ for _i in range(256):
     _TABLE.append(_c)
 
 
-def crc32c(data):
+def _crc32c_py(data):
     crc = 0xFFFFFFFF
     for b in data:
         crc = _TABLE[(crc ^ b) & 0xFF] ^ (crc >> 8)
     return crc ^ 0xFFFFFFFF
+
+
+_native = None
+
+
+def crc32c(data):
+    """CRC-32C of a bytes-like object: the library's host routine (fact_crc32c, slicing-by-8) for anything large,
+    the table loop above for small inputs or when the library is not built."""
+    global _native
+    if len(data) < 4096:
+        return _crc32c_py(data)
+    if _native is None:
+        try:
+            from mint_amd import _lib
+            _native = _lib.lib().fact_crc32c
+        except Exception:
+            _native = False
+    if not _native:
+        return _crc32c_py(data)
+    import ctypes
+    buf = bytes(data) if not isinstance(data, (bytes, bytearray)) else data
+    arr = (ctypes.c_char * len(buf)).from_buffer_copy(buf) if isinstance(buf, bytearray) else buf
+    return int(_native(arr, len(buf), 0)) & 0xFFFFFFFF
 
 
 def _masked(data):

@@ -3,6 +3,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from mint_amd.checkpoint import CheckpointManager
@@ -52,3 +53,41 @@ def test_checkpoint_interval_keep_and_resume(tmp_path):
     m2, o2 = _FakeModel(), Adam(1e-3)
     assert CheckpointManager(m2, o2, str(tmp_path)).restore_or_initialize().endswith("ckpt-40.pt")
     assert o2.iterations == 40 and float(m2.w[0]) == 40.0
+
+
+@pytest.mark.gpu
+def test_tf_object_graph_checkpoint_export_import_on_engine(tmp_path):
+    """Row f3 on the engine: a trained model (weights, Adam m / v, iteration counter) written as a TensorFlow
+    object-graph checkpoint with the reference's variable paths (mint_amd/tf_checkpoint.py) and imported into a fresh
+    model reproduces the forward pass exactly and continues training identically."""
+    import torch
+    from mint_amd import checkpoint, configs, model_builder
+    from mint_amd.trainer import Adam, SingleTaskTrainer
+    from oracle import fact_oracle as O
+    cfg = O.TINY_CFG
+    batch = {k: v.float().cuda() for k, v in O.synthetic_batch(cfg, 4, 8, seed=2).items()}
+
+    def make():
+        m = model_builder.build(configs.tiny_fact(), True)
+        m.build(4, 225, 35)
+        return m
+    a = make()
+    opt_a = Adam(1e-3)
+    tr_a = SingleTaskTrainer([batch], "target", a, optimizer=opt_a)
+    for _ in range(3):
+        tr_a.train_step(iter([batch]))
+    prefix = checkpoint.export_tf_checkpoint(a, str(tmp_path / "ckpt-3"), opt_a)
+    b = make()
+    opt_b = Adam(1e-3)
+    assert checkpoint.import_tf_checkpoint(b, str(tmp_path), opt_b, verify_crc=True) == prefix
+    assert opt_b.iterations == opt_a.iterations == 3
+    inp = {k: v for k, v in batch.items() if k != "target"}
+    assert torch.equal(a(inp), b(inp))
+    for arena in ("params", "adam_m", "adam_v"):
+        assert torch.equal(a._arena[arena], b._arena[arena]), arena
+    tr_b = SingleTaskTrainer([batch], "target", b, optimizer=opt_b)
+    la, lb = float(tr_a.train_step(iter([batch]))), float(tr_b.train_step(iter([batch])))
+    # (the training step sums split-K partials with fp32 atomics: equal up to summation order, not bit for bit)
+    assert abs(la - lb) < 1e-5 * abs(la), (la, lb)
+    d = (a._arena["params"] - b._arena["params"]).norm() / a._arena["params"].norm()
+    assert float(d) < 1e-5, float(d)
