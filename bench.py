@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--fuse-optimizer", type=int, default=1, help="0 = Adam as a separate pass after backward (A/B knob)")
     ap.add_argument("--mode", choices=["train", "ar", "scaled"], default="train")
     ap.add_argument("--profile-steps", type=int, default=4, help="extra steps for the in-step kernel table")
+    ap.add_argument("--parity", action="store_true",
+                    help="--mode scaled: also run ONE full-depth step at batch 1 against the fp32 CPU oracle "
+                         "(loss and every gradient tensor; takes a few minutes of host time)")
     ap.add_argument("--grad-buckets", choices=["bf16", "fp32"], default="bf16",
                     help="N > 1: dtype of the all-reduced gradient buckets (bf16: 240.8 MB per step, fp32: 481.6 MB)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
@@ -243,6 +246,9 @@ def run_scaled(args, device):
         loss = tr.train_step(it)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    parity = None
+    if args.parity:
+        parity = scaled_parity(model, device)
     d, ff, n = 1536, 6144, 1440
     lin = lambda tokens, layers: 2.0 * tokens * layers * (4 * d * d + 2 * d * ff)
     attn = lambda tok, layers: 4.0 * tok * tok * d * layers
@@ -257,7 +263,41 @@ def run_scaled(args, device):
         "config": {"workload": "scaled FACT train step (BASELINE.json configs[4], per-GPU share)", "per_gpu_batch": B,
                    "motion_seq": 480, "audio_seq": 960, "hidden": d, "cross_layers": 24, "params": nparams},
         "step_tflops": round(step_flop / dt / 1e12, 1),
-        "step_mfma_frac": round(step_flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(float(loss), 5)}))
+        "step_mfma_frac": round(step_flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(float(loss), 5),
+        "parity_vs_oracle": parity}))
+
+
+def scaled_parity(model, device):
+    """One FULL-DEPTH scaled-FACT step (2 + 2 + 24 layers, d = 1536, n = 1440: tiled attention kernels) at batch 1
+    on the engine vs the fp32 PyTorch-CPU oracle with the same weights and inputs: loss and all gradient tensors."""
+    from oracle import fact_oracle as O
+    cfg = {"motion": {"seq_len": 480, "feature_dim": 225, "hidden": 1536, "layers": 2, "heads": 12, "ff": 6144},
+           "audio": {"seq_len": 960, "feature_dim": 35, "hidden": 1536, "layers": 2, "heads": 12, "ff": 6144},
+           "cross": {"hidden": 1536, "layers": 24, "heads": 12, "ff": 6144}, "out_dim": 225}
+    batch = O.synthetic_batch(cfg, 1, TARGET_LEN, seed=0, dtype=torch.float32)
+    gb = {k: v.float().to(device) for k, v in batch.items()}
+    params = {n: v.detach().cpu().float().clone() for n, v in zip(model.variable_names, model.trainable_variables)}
+    model.grad_arena.zero_()
+    t0 = time.perf_counter()
+    loss = float(model.forward_backward({k: v for k, v in gb.items() if k != "target"}, gb["target"]))
+    torch.cuda.synchronize()
+    grads = [g.detach().cpu().double().flatten() for g in model.gradients]
+    model.grad_arena.zero_()
+    torch.set_num_threads(min(usable_cores(), 64))
+    ref_loss, ref_grads, _ = O.loss_and_grads(params, cfg, batch["motion_input"], batch["audio_input"], batch["target"])
+    worst_cos, worst_rel, worst_name = 1.0, 0.0, ""
+    for name, g in zip(model.variable_names, grads):
+        r = ref_grads[name].double().flatten()
+        c = float((g @ r) / (g.norm() * r.norm() + 1e-30))
+        rl = float((g - r).norm() / (r.norm() + 1e-30))
+        if c < worst_cos:
+            worst_cos, worst_name = c, name
+        worst_rel = max(worst_rel, rl)
+    return {"batch": 1, "layers": "2+2+24", "loss_engine": round(loss, 6), "loss_oracle": round(float(ref_loss), 6),
+            "loss_rel_diff": round(abs(loss - float(ref_loss)) / abs(float(ref_loss)), 6),
+            "gradient_tensors": len(grads), "worst_gradient_cosine": round(worst_cos, 5),
+            "worst_gradient_cosine_tensor": worst_name, "worst_gradient_rel_frobenius": round(worst_rel, 4),
+            "oracle": "fp32 PyTorch-CPU restatement (oracle/fact_oracle.py)", "seconds": round(time.perf_counter() - t0, 1)}
 
 
 def main():
