@@ -158,6 +158,7 @@ struct BwScratch {
   bf16_t* dh2_pp[kBwBuf] = {};    // dgrad outputs feeding the two LayerNorm backward kernels (also read by the
   bf16_t* dh1_pp[kBwBuf] = {};    //   parameter-gradient column sums on the wgrad stream)
   hipEvent_t ev_batch[kBwBuf] = {};  // wgrad batch of the last layer of parity q finished
+  hipEvent_t ev_waited = nullptr;    // last batch event the chain has already waited for
   PendingBatch pend;
   unsigned bw_i = 0;
   float* slab = nullptr;      // split-K slabs of this chain's wgrad GEMMs (null = the handle's)
@@ -1029,7 +1030,7 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   bf16_t* dh2 = split ? sc.dh2_pp[q] : sc.dh;
   bf16_t* dh1 = split ? sc.dh1_pp[q] : sc.dh;
   const bf16_t* xin16 = dx16;
-  if (two && sc.ev_batch[q]) (void)hipStreamWaitEvent(s, sc.ev_batch[q], 0);
+  if (two && sc.ev_batch[q] && sc.ev_batch[q] != sc.ev_waited) (void)hipStreamWaitEvent(s, sc.ev_batch[q], 0);
   // ---- MLP block: x_out = x_mid + W2 gelu(W1 LN2(x_mid) + b1) + b2
   const double Md = (double)M, fl_attn = 4.0 * (double)B * st.H * (double)st.n * st.n * st.dh;
   {
@@ -1085,7 +1086,10 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   }
   // readers of the previous contents of xb[q]: the batch of the layer two steps back
   const int qr = (q + 1) % kBwBuf;  // parity of layer+2 == parity of layer-1
-  if (two && sc.ev_batch[qr]) (void)hipStreamWaitEvent(s, sc.ev_batch[qr], 0);
+  if (two && sc.ev_batch[qr]) {
+    (void)hipStreamWaitEvent(s, sc.ev_batch[qr], 0);
+    sc.ev_waited = sc.ev_batch[qr];  // the next layer's entry wait is for this same event
+  }
   KScope kln1(h, KP_LN_BWD, s, 0, Md * d * 16.0);
   if (split)
     CHK(launch_ln_bwd_dx(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, M, d, dp, s));
@@ -1662,8 +1666,10 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
     h->adam_pending = false;
   }
   // the caller's stream has joined the side stream: no reader of the backward scratch is left
-  for (BwScratch& sc : h->bw)
+  for (BwScratch& sc : h->bw) {
     for (int q = 0; q < kBwBuf; ++q) sc.ev_batch[q] = nullptr;
+    sc.ev_waited = nullptr;
+  }
   return 0;
 }
 
