@@ -141,9 +141,13 @@ class OverlappedGradReducer:
     def finish(self):
         arena = self.model.grad_arena
         for w, offset, count, buf in self.works:
-            w.wait()  # current (compute) stream waits for the collective
-            if buf is not None:
+            if buf is None:
+                w.wait()  # current (compute) stream waits for the collective
+            else:
+                # the cast back runs on the COMMUNICATION stream: that stream has to wait for the collective (RCCL runs
+                # it on its own stream); the compute stream joins the communication stream below
                 with self._stream():
+                    w.wait()
                     self.model.cast_bucket_from_bf16(buf, arena[offset:offset + count], self.comm)
         self.works = []
         self.buckets_seen = []
