@@ -22,17 +22,22 @@ CFG = {  # smaller than TINY to keep the CPU suite fast
 
 
 def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+    """A rendezvous FILE, not a TCP port: picking a free port and handing it to two spawned processes races with
+    everything else on the host (seen as a rare spurious failure); a file store has no such window."""
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix="mint_amd_rdzv_")
+    os.close(fd)
+    os.remove(path)  # the file store creates it
+    return path
+
+
+def _init(rank, world, path):
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+    dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
 
 
 def _worker(rank, world, port, q):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     torch.set_num_threads(1)
     full = O.synthetic_batch(CFG, 4, 4, seed=3)
     mine = {k: v[2 * rank:2 * rank + 2] for k, v in full.items()}
@@ -74,9 +79,7 @@ def test_two_replicas_match_single_process_global_batch():
 def _worker_overlap(rank, world, port, q, bf16):
     """The REAL OverlappedGradReducer (bucket callback protocol, async all-reduces in flight while later buckets
     are still being produced, finish() before the optimizer) under world_size 2."""
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    _init(rank, world, port)
     torch.set_num_threads(1)
     full = O.synthetic_batch(CFG, 4, 4, seed=3)
     mine = {k: v[2 * rank:2 * rank + 2] for k, v in full.items()}
