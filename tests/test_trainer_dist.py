@@ -31,6 +31,11 @@ def _free_port():
     return path
 
 
+def _plain(metrics):
+    """metric values as Python floats (no tensors through the multiprocessing queue)"""
+    return {k: (float(v) if torch.is_tensor(v) else v) for k, v in metrics.items()} if isinstance(metrics, dict) else metrics
+
+
 def _init(rank, world, path):
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
@@ -45,7 +50,9 @@ def _worker(rank, world, port, q):
     trainer = SingleTaskTrainer([mine, mine], "target", model, optimizer=Adam(1e-2))
     assert trainer.num_replicas_in_sync == 2
     hist = train(trainer, steps=2, steps_per_loop=2)
-    q.put((rank, model.flat_params(), hist[-1][1]))
+    # numpy, not a tensor: a tensor crosses the queue as a shared-memory fd that dies with this process (rare
+    # ConnectionResetError in the parent when the worker exits first)
+    q.put((rank, model.flat_params().detach().cpu().numpy().copy(), _plain(hist[-1][1])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -60,7 +67,7 @@ def test_two_replicas_match_single_process_global_batch():
     res = {}
     for _ in range(2):
         rank, flat, metrics = q.get(timeout=240)
-        res[rank] = (flat.clone(), metrics)
+        res[rank] = (torch.from_numpy(flat).clone(), metrics)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -100,7 +107,7 @@ def _worker_overlap(rank, world, port, q, bf16):
     model.set_grad_callback(spy, None)         # observe the second step's bucket traffic
     trainer.train_step()
     metrics = trainer.train_loop_end()
-    q.put((rank, model.flat_params(), metrics, seen, list(model.buckets)))
+    q.put((rank, model.flat_params().detach().cpu().numpy().copy(), _plain(metrics), seen, list(model.buckets)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -116,7 +123,7 @@ def test_overlapped_reducer_world2(bf16):
     res = {}
     for _ in range(2):
         rank, flat, metrics, seen, buckets = q.get(timeout=240)
-        res[rank] = (flat.clone(), metrics, seen, buckets)
+        res[rank] = (torch.from_numpy(flat).clone(), metrics, seen, buckets)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
