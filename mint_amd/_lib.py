@@ -110,6 +110,9 @@ def lib():
             raise RuntimeError(
                 "HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`"
                 " (there is no CPU fallback)" % LIB_PATH)
+        # PyTorch-ROCm first: it brings its own HIP runtime, and the library must bind to THAT instance (loaded the
+        # other way round the process ends up with two runtimes and the engine sees "no ROCm-capable device")
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
