@@ -121,6 +121,48 @@ def kernel_table(model, step_fn, nsteps):
     return rows, tot / nsteps
 
 
+def wgrad_standalone(device, K=5760, d=800, ff=3072, iters=20):
+    """The dominant kernel ALONE on the chip: one grouped whole-K launch of a cross-modal layer's four weight gradients
+    (190 tiles of 160x256), HIP events on the launch stream.  In the step the same kernel runs as two 95-workgroup
+    launches beside the dgrad chain, so its in-step per-launch rate (the `roofline` figures) is bounded by the 37 % of
+    the CUs it is given; this is the rate of the kernel itself."""
+    import ctypes as C
+    from mint_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator(device=device).manual_seed(1)
+    rp = lambda c: (c + 63) // 64 * 64
+
+    def mk(cols):
+        t = torch.zeros(K, rp(cols), device=device, dtype=torch.bfloat16)
+        t[:, :cols] = torch.randn(K, cols, device=device, generator=g).to(torch.bfloat16)
+        return t
+    xin, gact, h2, dpre, att, xmid, h1, dqkv = mk(d), mk(ff), mk(d), mk(ff), mk(d), mk(d), mk(d), mk(3 * d)
+    outs = [torch.zeros(ff, d, device=device), torch.zeros(d, ff, device=device), torch.zeros(d, d, device=device),
+            torch.zeros(d, 3 * d, device=device)]
+    probs = [(xin, d, gact, ff, outs[0], 1), (h2, d, dpre, ff, outs[1], 0), (att, d, xmid, d, outs[2], 0),
+             (h1, d, dqkv, 3 * d, outs[3], 0)]
+    n = 4
+    VP, IA = C.c_void_p * n, C.c_int * n
+    a_ = VP(*[q[0].data_ptr() for q in probs]); lda = IA(*[q[0].stride(0) for q in probs])
+    b_ = VP(*[q[2].data_ptr() for q in probs]); ldb = IA(*[q[2].stride(0) for q in probs])
+    o_ = VP(*[q[4].data_ptr() for q in probs]); ldo = IA(*[q[4].stride(0) for q in probs])
+    mo = IA(*[q[1] for q in probs]); no = IA(*[q[3] for q in probs]); tr = IA(*[q[5] for q in probs])
+    run = lambda: L.check(lib.fact_op_gemm_tn_group(n, a_, lda, b_, ldb, o_, ldo, mo, no, tr, K, L.cur_stream()))
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    e1.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    flop = 2.0 * K * (2.0 * d * ff + 4.0 * d * d)
+    tf = flop / us / 1e6
+    return {"what": "one launch of all 190 tiles of a cross-modal layer (86.1 GFLOP), alone on the chip",
+            "avg_launch_us": round(us, 2), "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+
+
 def measured_traffic(name):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes, with provenance (file +
     commit); null when the committed profile is for another kernel."""
@@ -422,6 +464,11 @@ def main():
                            "how": "HIP events on the launch stream around every launch of the class, inside normal "
                                   "train steps (all streams overlapping); sum of kernel-class time per step "
                                   "%.2f ms vs %.2f ms wall" % (ksum_ms, ms_per_step)}
+        if top["name"] == "wgrad_group":
+            try:
+                out["roofline"]["standalone"] = wgrad_standalone(device)
+            except Exception as e:  # never lose the headline line to the extra measurement
+                out["roofline"]["standalone"] = {"error": repr(e)[:200]}
         by = {r["name"]: r for r in rows}
         if "attention_fwd" in by and "attention_bwd" in by:
             out["attention"] = {
