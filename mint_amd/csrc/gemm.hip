@@ -100,7 +100,12 @@ DEVINL void epilogue_store(const EpiParams& ep, int M, int N, int row, int col0,
     const int t = row - b * ep.n_tok;
     // three-way select on scalar pointers: indexing the by-value kernarg array with a per-lane value
     // makes hipcc spill the whole EpiParams to scratch (168-344 B/lane in round 1)
-    bf16_t* hr = (which == 0) ? ep.hrow[0] : (which == 1) ? ep.hrow[1] : ep.hrow[2];
+    // (and the three loads go through an opaque asm: otherwise LLVM folds the select of constant-index loads back
+    // into ONE dynamically indexed load and copies the kernarg struct to scratch after all - 176-392 B per lane)
+    unsigned long long h0 = (unsigned long long)ep.hrow[0], h1 = (unsigned long long)ep.hrow[1],
+                       h2 = (unsigned long long)ep.hrow[2];
+    asm volatile("" : "+s"(h0), "+s"(h1), "+s"(h2));
+    bf16_t* hr = reinterpret_cast<bf16_t*>((which == 0) ? h0 : (which == 1) ? h1 : h2);
     if (hr) {
       bf16x4 pk = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
       *reinterpret_cast<bf16x4*>(hr + ((size_t)(b * ep.heads + h) * ep.n_pad + t) * ep.dhp + d) = pk;
