@@ -1458,7 +1458,9 @@ size_t res_lds_bytes(int n, int which /*0 fwd, 1 dq, 2 dkdv*/) {
   if (which == 0) b = img + ((rows * DH * 2 + 1023) & ~(size_t)1023);
   else if (which == 1) b = 2 * img;
   else b = 2 * img + rows * 8;
-  if (rows > 384 || b > 160 * 1024 || g_attn_force_tiled) return 0;  // <= 12 waves (768 threads)
+  // <= 12 waves (768 threads, 168 registers): head dims above 96 need more registers than that (the DH = 128
+  // instantiations spilled 150-290 B per lane) and take the tiled kernels, which have no such limit
+  if (DH > 96 || rows > 384 || b > 160 * 1024 || g_attn_force_tiled) return 0;
   return b;
 }
 
@@ -1495,7 +1497,7 @@ int allow_lds_bytes(K kernel, bool* done, size_t bytes) {
 
 template <int DH>
 int fwd_t(const AttnParams& p, hipStream_t s) {
-  if (g_attn_variant == 2 && !g_attn_force_tiled) {
+  if constexpr (DH <= 96) if (g_attn_variant == 2 && !g_attn_force_tiled) {
     constexpr size_t lds = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG;
     static bool attr = false;
     if (int rc = allow_lds_bytes(attn_fwd_st_kernel<DH>, &attr, lds)) return rc;
@@ -1503,7 +1505,7 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
     return 0;
   }
   const size_t lds = res_lds_bytes<DH>(p.n, 0);
-  if (lds) {
+  if constexpr (DH <= 96) if (lds) {
     static bool attr = false;
     if (int rc = allow_big_lds(attn_fwd_res_kernel<DH>, &attr)) return rc;
     const int nw = ((p.n + 31) & ~31) / 32;
@@ -1516,7 +1518,7 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
 }
 template <int DH>
 int bwd_t(const AttnParams& p, hipStream_t s) {
-  if (g_attn_variant == 2 && !g_attn_force_tiled) {
+  if constexpr (DH <= 96) if (g_attn_variant == 2 && !g_attn_force_tiled) {
     constexpr size_t lds1 = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG, lds2 = (size_t)SG<DH>::NSLOT * (2 * SG<DH>::IMG + 256);
     static bool attr1 = false, attr2 = false;
     if (int rc = allow_lds_bytes(attn_bwd_dq_st_kernel<DH>, &attr1, lds1)) return rc;
@@ -1532,18 +1534,23 @@ int bwd_t(const AttnParams& p, hipStream_t s) {
   if (!lds1) hipLaunchKernelGGL(attn_bwd_prep_kernel<DH>, dim3((total + 255) / 256), dim3(256), 0, s, p);
   const int nw = ((p.n + 31) & ~31) / 32;
   dim3 grid((p.n + 127) / 128, p.B * p.H);
-  if (lds1) {
-    static bool attr = false;
-    if (int rc = allow_big_lds(attn_bwd_dq_res_kernel<DH>, &attr)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
+  if constexpr (DH <= 96) {
+    if (lds1) {
+      static bool attr = false;
+      if (int rc = allow_big_lds(attn_bwd_dq_res_kernel<DH>, &attr)) return rc;
+      hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
+    }
+    if (lds2) {
+      static bool attr = false;
+      if (int rc = allow_big_lds(attn_bwd_dkdv_res_kernel<DH>, &attr)) return rc;
+      hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel<DH>, dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
+    }
   } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
-  }
-  if (lds2) {
-    static bool attr = false;
-    if (int rc = allow_big_lds(attn_bwd_dkdv_res_kernel<DH>, &attr)) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel<DH>, dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
-  } else {
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
   }
   return 0;
