@@ -55,6 +55,7 @@ SIGNATURES = {
     "fact_adam_step": (_i, [_vp, _f, _f, _f, _f, _f, _vp]),
     "fact_adam_begin": (_i, [_vp, _f, _f, _f, _f]),
     "fact_adam_bucket": (_i, [_vp, _i, _vp]),
+    "fact_adam_bucket_bf16": (_i, [_vp, _i, _vp, _vp]),
     "fact_adam_cancel": (_i, [_vp]),
     "fact_num_buckets": (_i, [_vp, C.POINTER(_i)]),
     "fact_kprof": (_i, [_vp, _i]),

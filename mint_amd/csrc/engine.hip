@@ -640,13 +640,14 @@ int refresh_all(FactHandle* h, hipStream_t s) {
 }
 
 // Keras-Adam on one bucket (params, m, v updated; grads zeroed) + its shadow refresh
-int adam_bucket(FactHandle* h, int b, hipStream_t s) {
+int adam_bucket(FactHandle* h, int b, hipStream_t s, const bf16_t* g16 = nullptr) {
   const Bucket& k = h->buckets[b];
   const AdamArgs& a = h->adam;
-  KScope ks(h, KP_ADAM, s, 0, (double)k.cnt * 36.0);
+  KScope ks(h, KP_ADAM, s, 0, (double)k.cnt * (g16 ? 34.0 : 36.0));
   if (h->fuse_adam_cast)
     return launch_adam_fused(h->adam_blocks + k.blk_first, k.blk_n, h->params, h->adam_m, h->adam_v, h->grads,
-                             a.lr_t, a.b1, a.b2, a.eps, a.gscale, s);
+                             a.lr_t, a.b1, a.b2, a.eps, a.gscale, s, g16);
+  if (g16) return fail(-1, "bf16 gradient source needs the fused Adam + shadow kernel");
   CHK(launch_adam(h->params + k.off, h->adam_m + k.off, h->adam_v + k.off, h->grads + k.off, k.cnt, a.lr_t,
                   a.b1, a.b2, a.eps, a.gscale, s));
   return refresh_bucket(h, b, s);
@@ -1718,11 +1719,14 @@ int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps
   return 0;
 }
 
-int fact_adam_bucket(FactHandle* h, int bucket, void* stream) {
+int fact_adam_bucket(FactHandle* h, int bucket, void* stream) { return fact_adam_bucket_bf16(h, bucket, nullptr, stream); }
+
+int fact_adam_bucket_bf16(FactHandle* h, int bucket, const void* grads_bf16, void* stream) {
   if (!h) return fail(-1, "null handle");
   if (!h->adam_pending) return fail(-1, "fact_adam_bucket without fact_adam_begin");
   if (bucket < 0 || bucket >= (int)h->buckets.size()) return fail(-1, "bucket index out of range");
-  CHK(adam_bucket(h, bucket, (hipStream_t)stream));
+  if (grads_bf16 && ((uintptr_t)grads_bf16 & 7)) return fail(-1, "bf16 gradient buffer must be 8-byte aligned");
+  CHK(adam_bucket(h, bucket, (hipStream_t)stream, (const bf16_t*)grads_bf16));
   if (bucket == (int)h->buckets.size() - 1) h->adam_pending = false;
   return 0;
 }

@@ -89,8 +89,11 @@ struct AdamBlock {
   int r0, c0;
   int pad[4];
 };
+// `g16` != nullptr: gradients are read from that bf16 buffer (indexed like the arenas; the all-reduced bf16 bucket of
+// the data-parallel path) instead of from `g`; `g` is still zeroed.
 int launch_adam_fused(const AdamBlock* blocks, int nblocks, float* p, float* m, float* v, float* g,
-                      float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s);
+                      float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s,
+                      const bf16_t* g16 = nullptr);
 
 // f32 [R][C] -> bf16 dst [R][ldd] and bf16 dstT [C][ldt] (either may be null)
 int launch_cast_transpose(const float* src, int R, int C, bf16_t* dst, int ldd, bf16_t* dstT, int ldt,

@@ -498,18 +498,28 @@ DEVINL void adam1(float& p, float& m, float& v, float g, float lr_t, float b1, f
   p -= lr_t * m / (sqrtf(v) + eps);
 }
 
+// G16 != nullptr (data parallel with bf16 gradient buckets): the gradient is read from the all-reduced bf16 buffer
+// (indexed like the fp32 arena) instead of from G - no cast back into the arena; G is still zeroed for the next step.
+DEVINL float4 adam_grad4(const float* G, const bf16_t* G16, size_t o) {
+  if (G16) {
+    const bf16x4 g = *reinterpret_cast<const bf16x4*>(G16 + o);
+    return make_float4((float)g[0], (float)g[1], (float)g[2], (float)g[3]);
+  }
+  return *reinterpret_cast<const float4*>(G + o);
+}
+
 __global__ __launch_bounds__(256) void adam_fused_kernel(const AdamBlock* __restrict__ blocks,
                                                          float* __restrict__ P, float* __restrict__ Mm,
                                                          float* __restrict__ V, float* __restrict__ G,
-                                                         float lr_t, float b1, float b2, float eps,
-                                                         float gscale) {
+                                                         const bf16_t* __restrict__ G16, float lr_t, float b1,
+                                                         float b2, float eps, float gscale) {
   __shared__ float tile[64][65];
   const AdamBlock d = blocks[blockIdx.x];
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   if (d.R == 0) {  // flat segment
     for (int i = threadIdx.x * 4; i < d.C; i += 1024) {
       const size_t o = d.off + i;
-      float4 gv = *reinterpret_cast<const float4*>(G + o), mv = *reinterpret_cast<const float4*>(Mm + o);
+      float4 gv = adam_grad4(G, G16, o), mv = *reinterpret_cast<const float4*>(Mm + o);
       float4 vv = *reinterpret_cast<const float4*>(V + o), pv = *reinterpret_cast<const float4*>(P + o);
       adam1(pv.x, mv.x, vv.x, gv.x * gscale, lr_t, b1, b2, eps);
       adam1(pv.y, mv.y, vv.y, gv.y * gscale, lr_t, b1, b2, eps);
@@ -531,7 +541,9 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(const AdamBlock* __rest
     if (r < d.R) {
       const size_t o = d.off + (size_t)r * d.C + c;
       if (vec_ok && c + 3 < d.C) {
-        float4 gv = *reinterpret_cast<const float4*>(G + o), mv = *reinterpret_cast<const float4*>(Mm + o);
+        // (a tensor whose offset + row pitch is not 8-byte aligned in bf16 terms cannot occur: offsets are 64-float
+        //  aligned and this branch requires C % 4 == 0)
+        float4 gv = adam_grad4(G, G16, o), mv = *reinterpret_cast<const float4*>(Mm + o);
         float4 vv = *reinterpret_cast<const float4*>(V + o), pv = *reinterpret_cast<const float4*>(P + o);
         adam1(pv.x, mv.x, vv.x, gv.x * gscale, lr_t, b1, b2, eps);
         adam1(pv.y, mv.y, vv.y, gv.y * gscale, lr_t, b1, b2, eps);
@@ -549,7 +561,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(const AdamBlock* __rest
         for (int j = 0; j < 4; ++j)
           if (c + j < d.C) {
             float pv = P[o + j], mv = Mm[o + j], vv = V[o + j];
-            adam1(pv, mv, vv, G[o + j] * gscale, lr_t, b1, b2, eps);
+            adam1(pv, mv, vv, (G16 ? (float)G16[o + j] : G[o + j]) * gscale, lr_t, b1, b2, eps);
             P[o + j] = pv; Mm[o + j] = mv; V[o + j] = vv; G[o + j] = 0.f;
             w[j] = pv;
             d.s[(size_t)r * d.lds + c + j] = (bf16_t)pv;
@@ -926,9 +938,9 @@ int launch_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, fl
 }
 
 int launch_adam_fused(const AdamBlock* blocks, int nblocks, float* p, float* m, float* v, float* g,
-                      float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s) {
+                      float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s, const bf16_t* g16) {
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL(adam_fused_kernel, dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, lr_t, b1, b2, eps,
+  hipLaunchKernelGGL(adam_fused_kernel, dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t, b1, b2, eps,
                      gscale);
   return 0;
 }

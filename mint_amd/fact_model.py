@@ -285,8 +285,14 @@ class FACTModel:
         L.check(L.lib().fact_adam_cancel(self._h))
         self.global_step = int(global_step)
 
-    def adam_bucket(self, bucket, stream):
-        L.check(L.lib().fact_adam_bucket(self._h, int(bucket), C.c_void_p(stream.cuda_stream)))
+    def adam_bucket(self, bucket, stream, grads_bf16=None):
+        """Optimizer step of one gradient bucket on `stream` (after begin_fused_adam).  `grads_bf16`: a bf16 tensor
+        indexed like the gradient arena (the all-reduced communication buffer) to read the gradients from."""
+        if grads_bf16 is None:
+            L.check(L.lib().fact_adam_bucket(self._h, int(bucket), C.c_void_p(stream.cuda_stream)))
+        else:
+            L.check(L.lib().fact_adam_bucket_bf16(self._h, int(bucket), L.ptr(grads_bf16),
+                                                  C.c_void_p(stream.cuda_stream)))
 
     def apply_adam(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clip_norm=0.0):
         L.check(L.lib().fact_adam_step(self._h, float(lr), float(beta_1), float(beta_2), float(epsilon),

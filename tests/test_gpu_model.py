@@ -434,6 +434,28 @@ def test_overlapped_allreduce_callback_path_single_rank():
         assert torch.isfinite(g16).all()
         assert rel(g16, g_ref) < 4e-3, rel(g16, g_ref)
         assert torch.equal(g16, g16.to(torch.bfloat16).float()), "gradients did not pass through bf16"
+        # data-parallel optimizer placement: Adam of every bucket right behind its all-reduce on the communication
+        # stream (what N > 1 runs; forced here at world size 1) must train exactly like all-reduce-then-one-Adam-pass
+        outs = []
+        for mode in (False, "force"):
+            for bf16 in (False, True):
+                m = model_builder.build(make_config(cfg), True)
+                tr = SingleTaskTrainer([batch] * 4, "target", m, optimizer=Adam(1e-3), overlap_grad_allreduce=True,
+                                       bf16_grad_buckets=bf16, dp_fused_adam=mode)
+                it = iter([batch] * 4)
+                ls = [float(tr.train_step(it)) for _ in range(4)]
+                torch.cuda.synchronize()
+                assert tr._reducer.fused_adam == bool(mode)
+                assert tr.optimizer.iterations == 4 and m.global_step == 4
+                outs.append((mode, bf16, ls, torch.cat([v.flatten() for v in m.trainable_variables]).cpu(),
+                             m._arena["adam_m"].cpu().clone(), float(m.grad_arena.abs().max())))
+        for bf16 in (False, True):
+            a = [o for o in outs if o[1] == bf16 and o[0] is False][0]
+            b = [o for o in outs if o[1] == bf16 and o[0] == "force"][0]
+            assert a[2] == pytest.approx(b[2], rel=1e-5), (a[2], b[2])
+            assert torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-6)
+            assert torch.allclose(a[4], b[4], rtol=1e-4, atol=1e-7)
+            assert b[5] == 0.0, "gradients not zeroed by the per-bucket optimizer step"
     finally:
         dist.destroy_process_group()
 
