@@ -257,6 +257,9 @@ struct FactHandle {
   hipStream_t aux = nullptr;  // stream of backward chain 1
   hipStream_t lite = nullptr; // column-sum kernels of the optimizer-only batches (beside the wgrad launches)
   int use_lite = 0;  // measured: no gain (round 2), off by default
+  int use_aux = 1;   // third stream for the motion stack's backward chain (0: on the caller's stream - the data-parallel
+                     // trainer sets it: with its communication stream and RCCL's own the process would have more
+                     // streams than the 4 hardware queues HIP gives it, and streams that share a queue serialise)
   int adam_hold = 1;          // in-backward optimizer: hold the head + cross buckets until the last is final
   // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
   fact_grad_cb cb = nullptr;
@@ -1540,6 +1543,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     h->wgrad_big = value;
     return 0;
   }
+  if (!strcmp(key, "aux_stream")) {
+    h->use_aux = value;
+    return 0;
+  }
   if (!strcmp(key, "side_stream")) {
     h->use_side = value;
     return 0;
@@ -1646,7 +1653,7 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   // handle's third stream (own scratch, chain 1) beside the audio stack's chain on the caller's stream;
   // both feed the one wgrad stream.  Alone, the 1920- and 3840-token GEMMs leave most of the chip idle
   // (the four encoder layers used to take 1.5 ms of a 10.4 ms step).
-  hipStream_t ms = (h->use_side && h->aux) ? h->aux : s;
+  hipStream_t ms = (h->use_side && h->use_aux && h->aux) ? h->aux : s;
   if (ms != s) stream_after(h, s, ms);
   // (audio first: its big-tile GEMMs need whole CUs; enqueued second they wait ~0.5 ms behind the motion
   //  chain's one-workgroup-per-CU kernels - rocprofv3 timeline, tools/tail_view.py)
@@ -1713,8 +1720,9 @@ int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps
   h->adam.b2 = beta2;
   h->adam.eps = eps;
   h->adam.gscale = 1.0f;
-  // created on first use (the default trainer never needs it)
-  if (!h->opt) HIPCHK(hipStreamCreateWithFlags(&h->opt, hipStreamNonBlocking));
+  // created on first use, and only when the engine itself will enqueue the updates (with a gradient callback the
+  // host calls fact_adam_bucket on its communication stream: one stream less competing for the hardware queues)
+  if (!h->opt && !h->cb) HIPCHK(hipStreamCreateWithFlags(&h->opt, hipStreamNonBlocking));
   h->adam_pending = true;
   return 0;
 }

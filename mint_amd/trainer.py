@@ -105,7 +105,7 @@ class OverlappedGradReducer:
     from the model, so tests/test_trainer_dist.py drives THIS class on CPU (gloo, world 2) with a stand-in
     that reports its buckets the way the engine does."""
 
-    def __init__(self, model, bf16_buckets=False):
+    def __init__(self, model, bf16_buckets=False, keep_streams_low=False):
         self.model = model
         self.bf16 = bool(bf16_buckets)
         self.comm = torch.cuda.Stream() if torch.cuda.is_available() else None
@@ -114,6 +114,16 @@ class OverlappedGradReducer:
         self._buf16 = None
         self.buckets_seen = []   # (bucket, offset, count) of the step in flight, in arrival order
         model.set_grad_callback(self._on_bucket, self.comm)
+        # This stream and RCCL's own join the engine's three: more streams than the 4 hardware queues HIP uses by
+        # default, and streams that share a queue serialise (one-GPU dry run with RCCL initialised, tools/dp_probe.py:
+        # 11.4 ms per step at GPU_MAX_HW_QUEUES = 4, 8.6 at 6, 8.2 at 7 - the single-replica speed - and 16.5 at 8).
+        # Launchers should export GPU_MAX_HW_QUEUES=7 before the HIP runtime starts (bench.py does for N > 1).
+        # `keep_streams_low` folds the engine's third stream instead (no measurable help at 4 queues: 11.4 vs 11.0).
+        if keep_streams_low and hasattr(model, "set_option"):
+            try:
+                model.set_option("aux_stream", 0)
+            except Exception:
+                pass
 
     def _stream(self):
         import contextlib
