@@ -71,6 +71,9 @@ def parse():
                          "(loss and every gradient tensor; takes a few minutes of host time)")
     ap.add_argument("--grad-buckets", choices=["bf16", "fp32"], default="bf16",
                     help="N > 1: dtype of the all-reduced gradient buckets (bf16: 240.8 MB per step, fp32: 481.6 MB)")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo = DRY RUN of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share "
+                         "devices, the collective goes through the host): the timing means nothing")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="engine option for A/B runs (fact_set_option), e.g. --opt wgrad_parts=1")
     return ap.parse_args()
@@ -355,12 +358,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    dry = args.dist_backend == "gloo"
+    if dry:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dry:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     if args.mode == "ar":
         return run_ar(args, device)
@@ -392,7 +402,8 @@ def main():
             return batch
 
     trainer = SingleTaskTrainer(Repeat(), "target", model, optimizer=opt, fuse_optimizer=bool(args.fuse_optimizer),
-                                bf16_grad_buckets=(world > 1 and args.grad_buckets == "bf16"))
+                                bf16_grad_buckets=(world > 1 and args.grad_buckets == "bf16"),
+                                overlap_grad_allreduce=(True if world > 1 else None))
     it = iter(Repeat())
 
     def sync():
@@ -459,6 +470,8 @@ def main():
                                     / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
         }
+        if dry:
+            out["dry_run"] = "gloo, ranks sharing devices: control-flow check of the N > 1 path, not a measurement"
         out["kernels"] = rows
         top = rows[0]
         traffic, src = measured_traffic(top["name"])
