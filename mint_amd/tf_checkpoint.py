@@ -19,7 +19,9 @@ variables.  This module
 Status: the container and the GPU boxes have no TensorFlow and the reference ships no checkpoint file, so the reader
 is verified against this module's own writer and against the published format descriptions only (table format:
 leveldb `doc/table_format.md`; bundle protos: tensorflow/core/protobuf/tensor_bundle.proto and
-trackable_object_graph.proto) - NOT yet against a TensorFlow-written file.  Snappy-compressed table blocks (TensorFlow
+trackable_object_graph.proto) - NOT yet against a TensorFlow-written file.  The wire encoding of every record this
+module writes is cross-checked against the official protobuf runtime (dynamic descriptors with those .proto files' field
+numbers: tests/test_tf_checkpoint.py::test_written_bundle_parses_with_the_official_protobuf_runtime).  Snappy-compressed table blocks (TensorFlow
 writes bundle indices uncompressed) are decoded through pyarrow when it is importable.
 """
 import os

@@ -166,3 +166,115 @@ def test_reader_follows_graph_edges_not_key_strings(tmp_path):
     assert ck["global_step"] == 777 and ck["iterations"] is None
     for n in shapes:
         np.testing.assert_array_equal(ck["params"][n], params[n])
+
+
+def _official_bundle_messages():
+    """BundleHeaderProto / BundleEntryProto / TrackableObjectGraph built with the OFFICIAL protobuf runtime from the field
+    numbers and types of tensorflow/core/protobuf/{tensor_bundle,trackable_object_graph}.proto and
+    framework/{tensor_shape,versions}.proto (restated here; TensorFlow itself is not installed)."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(name="mint_amd_test_tf_bundle.proto", package="tfb", syntax="proto3")
+
+    def msg(parent, name, fields):
+        m = parent.message_type.add() if isinstance(parent, descriptor_pb2.FileDescriptorProto) else parent.nested_type.add()
+        m.name = name
+        for fname, num, ftype, label, tname in fields:
+            f = m.field.add(name=fname, number=num, type=ftype, label=label)
+            if tname:
+                f.type_name = tname
+        return m
+    OPT, REP = F.LABEL_OPTIONAL, F.LABEL_REPEATED
+    shape = msg(fd, "TensorShapeProto", [("dim", 2, F.TYPE_MESSAGE, REP, ".tfb.TensorShapeProto.Dim"),
+                                         ("unknown_rank", 3, F.TYPE_BOOL, OPT, None)])
+    msg(shape, "Dim", [("size", 1, F.TYPE_INT64, OPT, None), ("name", 2, F.TYPE_STRING, OPT, None)])
+    msg(fd, "VersionDef", [("producer", 1, F.TYPE_INT32, OPT, None), ("min_consumer", 2, F.TYPE_INT32, OPT, None),
+                           ("bad_consumers", 3, F.TYPE_INT32, REP, None)])
+    msg(fd, "BundleHeaderProto", [("num_shards", 1, F.TYPE_INT32, OPT, None), ("endianness", 2, F.TYPE_INT32, OPT, None),
+                                  ("version", 3, F.TYPE_MESSAGE, OPT, ".tfb.VersionDef")])
+    msg(fd, "BundleEntryProto", [("dtype", 1, F.TYPE_INT32, OPT, None),
+                                 ("shape", 2, F.TYPE_MESSAGE, OPT, ".tfb.TensorShapeProto"),
+                                 ("shard_id", 3, F.TYPE_INT32, OPT, None), ("offset", 4, F.TYPE_INT64, OPT, None),
+                                 ("size", 5, F.TYPE_INT64, OPT, None), ("crc32c", 6, F.TYPE_FIXED32, OPT, None)])
+    graph = msg(fd, "TrackableObjectGraph", [("nodes", 1, F.TYPE_MESSAGE, REP, ".tfb.TrackableObjectGraph.TrackableObject")])
+    obj = msg(graph, "TrackableObject", [
+        ("children", 1, F.TYPE_MESSAGE, REP, ".tfb.TrackableObjectGraph.TrackableObject.ObjectReference"),
+        ("attributes", 2, F.TYPE_MESSAGE, REP, ".tfb.TrackableObjectGraph.TrackableObject.SerializedTensor"),
+        ("slot_variables", 3, F.TYPE_MESSAGE, REP, ".tfb.TrackableObjectGraph.TrackableObject.SlotVariableReference")])
+    msg(obj, "ObjectReference", [("node_id", 1, F.TYPE_INT32, OPT, None), ("local_name", 2, F.TYPE_STRING, OPT, None)])
+    msg(obj, "SerializedTensor", [("name", 1, F.TYPE_STRING, OPT, None), ("full_name", 2, F.TYPE_STRING, OPT, None),
+                                  ("checkpoint_key", 3, F.TYPE_STRING, OPT, None)])
+    msg(obj, "SlotVariableReference", [("original_variable_node_id", 1, F.TYPE_INT32, OPT, None),
+                                       ("slot_name", 2, F.TYPE_STRING, OPT, None),
+                                       ("slot_variable_node_id", 3, F.TYPE_INT32, OPT, None)])
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    get = lambda n: message_factory.GetMessageClass(pool.FindMessageTypeByName("tfb." + n))
+    return get("BundleHeaderProto"), get("BundleEntryProto"), get("TrackableObjectGraph")
+
+
+def test_written_bundle_parses_with_the_official_protobuf_runtime(tmp_path):
+    """The hand-rolled encoders of mint_amd/tf_checkpoint.py against google.protobuf: every index record of a written
+    checkpoint parses as BundleHeaderProto / BundleEntryProto, the object graph parses as TrackableObjectGraph, and walking
+    the OFFICIAL message's edges reaches the same checkpoint keys, slot variables and data-file extents our reader uses."""
+    pytest.importorskip("google.protobuf")
+    Header, Entry, Graph = _official_bundle_messages()
+    shapes, params, m, v = _tiny_state(3)
+    prefix = str(tmp_path / "ckpt-7")
+    T.write_fact_checkpoint(prefix, params, m, v, iterations=7)
+    table = dict(T.read_table(prefix + ".index"))
+    hdr = Header()
+    hdr.ParseFromString(table[b""])
+    assert hdr.num_shards == 1 and hdr.endianness == 0 and hdr.version.producer >= 1
+    data = open(prefix + ".data-00000-of-00001", "rb").read()
+    rd = T.TensorBundleReader(prefix)
+    n_entries = 0
+    for key, val in table.items():
+        if key == b"":
+            continue
+        e = Entry()
+        e.ParseFromString(val)
+        assert e.SerializeToString() == val or Entry.FromString(e.SerializeToString()) == e   # canonical or equivalent
+        assert e.shard_id == 0 and 0 <= e.offset and e.offset + e.size <= len(data)
+        dims = tuple(d.size for d in e.shape.dim)
+        if e.dtype == T.DT_FLOAT:
+            assert e.size == 4 * int(np.prod(dims, dtype=np.int64))
+            arr = np.frombuffer(data, "<f4", count=e.size // 4, offset=e.offset).reshape(dims)
+            np.testing.assert_array_equal(arr, rd.get(key.decode(), verify_crc=True))
+        # crc32c field: masked crc of the tensor bytes, as our reader checks it
+        from mint_amd.tfrecord import _masked
+        if e.dtype != T.DT_STRING:
+            assert e.crc32c == _masked(data[e.offset:e.offset + e.size])
+        n_entries += 1
+    assert n_entries == 3 * len(shapes) + 1 + 1   # params + m + v, optimizer/iter, the object graph
+    g = Graph()
+    g.ParseFromString(rd.get(T.OBJECT_GRAPH_KEY))
+    assert len(g.nodes) > len(shapes)
+
+    def walk(path):
+        nid = 0
+        for part in path:
+            nxt = [c.node_id for c in g.nodes[nid].children if c.local_name == part]
+            assert len(nxt) == 1, (path, part)
+            nid = nxt[0]
+        return nid
+    ours = T.ObjectGraph(rd.get(T.OBJECT_GRAPH_KEY))
+    for name in shapes:
+        path = ["model"] + T.tf_variable_path(name)
+        nid = walk(path)
+        keys = [a.checkpoint_key for a in g.nodes[nid].attributes if a.name == "VARIABLE_VALUE"]
+        assert len(keys) == 1 and keys[0].endswith(T.VAR_SUFFIX)
+        assert ours.walk(path) == nid and ours.variable_key(nid) == keys[0]
+        np.testing.assert_array_equal(rd.get(keys[0]), params[name])
+    # Adam slots hang off the optimizer node and point at (variable node, slot node) pairs
+    opt = g.nodes[walk(["optimizer"])]
+    slots = {(s.original_variable_node_id, s.slot_name): s.slot_variable_node_id for s in opt.slot_variables}
+    assert len(slots) == 2 * len(shapes)
+    name = list(shapes)[5]
+    vid = walk(["model"] + T.tf_variable_path(name))
+    for slot_name, ref in (("m", m), ("v", v)):
+        sid = slots[(vid, slot_name)]
+        key = [a.checkpoint_key for a in g.nodes[sid].attributes if a.name == "VARIABLE_VALUE"][0]
+        np.testing.assert_array_equal(rd.get(key), ref[name])
+    it = [a.checkpoint_key for a in g.nodes[walk(["optimizer", "iter"])].attributes][0]
+    assert int(rd.get(it).reshape(-1)[0]) == 7
