@@ -71,10 +71,16 @@ def prefetch(gen, depth=2):
 
 
 def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_training=True, use_tpu=False,
-                 device=None, seed=None, prefetch_batches=2):
+                 device=None, seed=None, prefetch_batches=2, cache_decoded_bytes=8 << 30):
     """Generator of feature dicts (inputs.py:20-123). Training: shuffle(100), repeat forever,
     drop the remainder; eval: one pass in file order, remainder kept.  `prefetch_batches` > 0 stages that many
-    batches ahead on a background thread (the reference's `ds.prefetch`); 0 = synchronous."""
+    batches ahead on a background thread (the reference's `ds.prefetch`); 0 = synchronous.
+
+    `cache_decoded_bytes`: training repeats the files forever and cuts ONE 360-frame window out of a multi-thousand
+    frame track per visit, so the decoded tracks of a file are kept (up to this many bytes in total; 0 = re-read and
+    re-parse every epoch like tf.data does).  One MI355X consumes ~2 000 windows/s (bench.py); parsing a 2.3 MB
+    Example per window in Python delivers ~1 300/s, windows cut from cached tracks ~9 000/s (tools/input_bench.py).
+    Order, shuffling and the random windows are unchanged by the cache."""
     batch_size = train_eval_config.batch_size
     files = sorted(_glob.glob(dataset_config.data_files))
     if not files:
@@ -86,6 +92,25 @@ def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_traini
     rng = np.random.RandomState(seed)
     pyrng = random.Random(seed)
 
+    cache, cached = {}, [0]
+
+    def decoded(path):
+        """decoded records of one file, from the cache when the file has been seen (training only)"""
+        if path in cache:
+            yield from cache[path]
+            return
+        keep = [] if (is_training and cache_decoded_bytes > 0) else None
+        for payload in tfrecord.read_records(path):
+            ex = _decode(payload, list(params))
+            if keep is not None:
+                keep.append(ex)
+            yield ex
+        if keep is not None:
+            size = sum(v.nbytes for ex in keep for v in ex.values() if isinstance(v, np.ndarray))
+            if cached[0] + size <= cache_decoded_bytes:
+                cache[path] = keep
+                cached[0] += size
+
     def examples():
         while True:
             order = list(files)
@@ -93,8 +118,7 @@ def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_traini
                 pyrng.shuffle(order)
             buf = []
             for path in order:
-                for payload in tfrecord.read_records(path):
-                    ex = _decode(payload, list(params))
+                for ex in decoded(path):
                     if use_fact:
                         ex = inputs_util.fact_preprocessing(ex, params, is_training, rng)
                     if not is_training:

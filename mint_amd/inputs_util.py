@@ -32,7 +32,9 @@ def fact_preprocessing(example, modality_to_params, is_training, rng=None):
     motion = np.asarray(example.pop("motion_sequence"), dtype=np.float32)
     audio = np.asarray(example.pop("audio_sequence"), dtype=np.float32)
     mp, ap = modality_to_params["motion"], modality_to_params["audio"]
-    motion = np.pad(motion, [[0, 0], [6, 0]])
+    # (the reference pads the whole sequence and then cuts windows; cutting first gives the same windows without
+    # copying a multi-thousand-frame track per sample)
+    pad = lambda w: np.pad(w, [[0, 0], [6, 0]])
     if is_training:
         window = max(mp["input_length"], mp["target_shift"] + mp["target_length"], ap["input_length"])
         hi = motion.shape[0] - window + 1
@@ -42,10 +44,10 @@ def fact_preprocessing(example, modality_to_params, is_training, rng=None):
         start = int(rng.randint(0, hi))
     else:
         start = 0
-    example["motion_input"] = motion[start:start + mp["input_length"]]
+    example["motion_input"] = pad(motion[start:start + mp["input_length"]])
     if is_training:
         s = start + mp["target_shift"]
-        example["target"] = motion[s:s + mp["target_length"]]
+        example["target"] = pad(motion[s:s + mp["target_length"]])
         example["audio_input"] = audio[start:start + ap["input_length"]]
     else:
         example["audio_input"] = audio

@@ -104,6 +104,7 @@ def _ld(num, payload):
 def parse_example(payload):
     """tf.train.Example bytes -> {name: list[bytes] | np.float32 array | np.int64 array}."""
     out = {}
+    payload = memoryview(payload)  # nested length-delimited fields are sliced without copying (a record is megabytes)
     for num, wt, features in _fields(payload):
         if num != 1 or wt != 2:
             continue
@@ -124,8 +125,8 @@ def parse_example(payload):
                     parts = []
                     for n, w, v in _fields(kv):
                         if n == 1:
-                            parts.append(np.frombuffer(bytes(v), dtype="<f4"))
-                    value = np.concatenate(parts) if parts else np.zeros(0, np.float32)
+                            parts.append(np.frombuffer(v, dtype="<f4"))  # packed: a view into the record
+                    value = (parts[0] if len(parts) == 1 else np.concatenate(parts)) if parts else np.zeros(0, np.float32)
                 elif knum == 3:  # Int64List (packed or not)
                     vals = []
                     for n, w, v in _fields(kv):
@@ -135,7 +136,6 @@ def parse_example(payload):
                             vals.append(v)
                         else:
                             p = 0
-                            v = bytes(v)
                             while p < len(v):
                                 x, p = _varint(v, p)
                                 vals.append(x)

@@ -210,3 +210,29 @@ def test_reader_parses_examples_encoded_by_the_official_protobuf_runtime(tmp_pat
         assert ex["motion_name"].startswith("gBR_sBM") and ex["audio_name"].startswith("mBR")
         np.testing.assert_array_equal(ex["motion_sequence"], motion)
         np.testing.assert_array_equal(ex["audio_sequence"], audio)
+
+
+def test_decoded_track_cache_does_not_change_the_stream(tmp_path):
+    """create_input(cache_decoded_bytes=...) keeps decoded tracks across epochs; batches, order and random windows must be
+    exactly those of the re-parse-every-epoch pipeline (same seed), over several passes of the files."""
+    rng = np.random.RandomState(1)
+    for f in range(2):
+        recs = []
+        for i in range(3):
+            n = 300 + 17 * i + 5 * f
+            m, a = rng.randn(n, 219).astype(np.float32), rng.randn(2 * n, 35).astype(np.float32)
+            recs.append(tfrecord.make_example({
+                "motion_name": "m%d_%d" % (f, i), "motion_sequence": m.flatten(), "motion_sequence_shape": np.array(m.shape),
+                "audio_name": "a%d_%d" % (f, i), "audio_sequence": a.flatten(), "audio_sequence_shape": np.array(a.shape)}))
+        tfrecord.write_records(str(tmp_path / ("aist_tfrecord-train-%d" % f)), recs)
+    cfg = _dataset_cfg(str(tmp_path / "*_tfrecord-train*"))
+    tc = protos.TrainConfig()
+    tc.batch_size = 4
+    streams = [inputs.create_input(tc, cfg, is_training=True, seed=5, prefetch_batches=0, cache_decoded_bytes=c)
+               for c in (0, 1 << 30, 200_000)]   # off, everything cached, room for one file only
+    for _ in range(9):   # 36 samples = 6 passes over the 6 tracks
+        ref, full, part = [next(s) for s in streams]
+        for other in (full, part):
+            assert other["motion_name"] == ref["motion_name"] and other["audio_name"] == ref["audio_name"]
+            for k in ("motion_input", "audio_input", "target"):
+                assert np.array_equal(other[k].numpy(), ref[k].numpy()), k
