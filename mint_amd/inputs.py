@@ -70,6 +70,58 @@ def prefetch(gen, depth=2):
     return consume()
 
 
+_EVENT = "__copy_done__"
+
+
+class _DeviceStager:
+    """Host-to-device staging of batches: a ring of PRE-PINNED host buffers and a dedicated copy stream; the consumer's
+    stream waits for the batch's event (`_join_copies`).  Measured on MI355X (tools/e2e_probe.py, fact_v5 B = 16 train
+    step): resident batch 8.01 ms; this scheme 8.02 ms; `pin_memory().to(device, non_blocking=True)` per batch - the
+    round-1 code - 16.7 ms (the freshly pinned temporary is released while its copy is in flight); pageable `.to(device)`
+    8.19 ms."""
+
+    def __init__(self, device, slots):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.ring = [dict() for _ in range(max(2, slots))]
+        self.events = [None] * len(self.ring)
+        self.i = 0
+
+    def stage(self, arrays):
+        """{key: list of equally shaped numpy arrays} -> ({key: device tensor}, event recorded behind the copies)"""
+        i, self.i = self.i, (self.i + 1) % len(self.ring)
+        if self.events[i] is not None:
+            self.events[i].synchronize()  # the copies that last read this slot's pinned buffers are done
+        out = {}
+        with torch.cuda.stream(self.stream):
+            for k, parts in arrays.items():
+                shape = (len(parts),) + tuple(parts[0].shape)
+                dtype = torch.from_numpy(np.empty(0, parts[0].dtype)).dtype
+                pinned = self.ring[i].get(k)
+                if pinned is None or tuple(pinned.shape) != shape or pinned.dtype != dtype:
+                    pinned = self.ring[i][k] = torch.empty(shape, dtype=dtype, pin_memory=True)
+                np.stack(parts, out=pinned.numpy())
+                out[k] = pinned.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.events[i] = ev
+        return out, ev
+
+
+def _join_copies(gen):
+    """Consumer side of `_DeviceStager`: the consumer's current stream waits for the batch's copies, and the device tensors
+    (allocated on the copy stream) are marked as used by that stream."""
+    for batch in gen:
+        ev = batch.pop(_EVENT, None)
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for v in batch.values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
+        yield batch
+
+
 def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_training=True, use_tpu=False,
                  device=None, seed=None, prefetch_batches=2, cache_decoded_bytes=8 << 30):
     """Generator of feature dicts (inputs.py:20-123). Training: shuffle(100), repeat forever,
@@ -133,15 +185,18 @@ def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_traini
                 return
 
     def collate(batch):
-        out = {}
+        out, arrays = {}, {}
         for k in batch[0]:
             if isinstance(batch[0][k], str):
                 out[k] = [b[k] for b in batch]
             else:
-                t = torch.from_numpy(np.stack([b[k] for b in batch]))
-                if device is not None:
-                    t = t.pin_memory().to(device, non_blocking=True) if torch.cuda.is_available() else t
-                out[k] = t
+                arrays[k] = [b[k] for b in batch]
+        if stager is not None:
+            tensors, ev = stager.stage(arrays)
+            out.update(tensors)
+            out[_EVENT] = ev
+        else:
+            out.update({k: torch.from_numpy(np.stack(v)) for k, v in arrays.items()})
         return out
 
     def batches():
@@ -154,4 +209,7 @@ def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_traini
         if batch and not is_training:
             yield collate(batch)
 
-    return prefetch(batches(), prefetch_batches) if prefetch_batches and prefetch_batches > 0 else batches()
+    depth = prefetch_batches if prefetch_batches and prefetch_batches > 0 else 0
+    stager = _DeviceStager(device, depth + 2) if (device is not None and torch.cuda.is_available()) else None
+    gen = prefetch(batches(), depth) if depth else batches()
+    return _join_copies(gen) if stager is not None else gen

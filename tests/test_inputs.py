@@ -236,3 +236,36 @@ def test_decoded_track_cache_does_not_change_the_stream(tmp_path):
             assert other["motion_name"] == ref["motion_name"] and other["audio_name"] == ref["audio_name"]
             for k in ("motion_input", "audio_input", "target"):
                 assert np.array_equal(other[k].numpy(), ref[k].numpy()), k
+
+
+@pytest.mark.gpu
+def test_device_staging_ring_delivers_the_cpu_stream(tmp_path):
+    """create_input(device=cuda): pre-pinned ring + copy stream + event hand-over (inputs._DeviceStager) must deliver exactly
+    the batches of the host pipeline, also after the ring wrapped around several times and with the consumer lagging."""
+    import torch
+    rng = np.random.RandomState(2)
+    recs = []
+    for i in range(6):
+        n = 300 + 11 * i
+        m, a = rng.randn(n, 219).astype(np.float32), rng.randn(2 * n, 35).astype(np.float32)
+        recs.append(tfrecord.make_example({
+            "motion_name": "m%d" % i, "motion_sequence": m.flatten(), "motion_sequence_shape": np.array(m.shape),
+            "audio_name": "a%d" % i, "audio_sequence": a.flatten(), "audio_sequence_shape": np.array(a.shape)}))
+    tfrecord.write_records(str(tmp_path / "aist_tfrecord-train-0"), recs)
+    cfg = _dataset_cfg(str(tmp_path / "*_tfrecord-train*"))
+    tc = protos.TrainConfig()
+    tc.batch_size = 4
+    for depth in (2, 0):
+        host = inputs.create_input(tc, cfg, is_training=True, seed=9, prefetch_batches=0)
+        dev = inputs.create_input(tc, cfg, is_training=True, seed=9, prefetch_batches=depth, device="cuda")
+        held = []
+        for step in range(14):
+            h, d = next(host), next(dev)
+            assert d["motion_name"] == h["motion_name"] and inputs._EVENT not in d
+            for k in ("motion_input", "audio_input", "target"):
+                assert d[k].is_cuda and torch.equal(d[k].cpu(), h[k]), (depth, step, k)
+            held.append((d, h))
+            if step % 5 == 4:
+                torch.cuda.synchronize()
+        for d, h in held:   # earlier batches were not overwritten by later copies
+            assert torch.equal(d["audio_input"].cpu(), h["audio_input"])
