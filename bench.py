@@ -243,6 +243,9 @@ def run_ar(args, device):
     inp = {"motion_input": torch.randn(B, 120, 225, generator=gen).to(device),
            "audio_input": torch.randn(B, 240 + steps - 1, 35, generator=gen).to(device)}
     model.build(B, 225, 35)
+    for kv in args.opt:
+        k, v = kv.split("=")
+        model.set_option(k, int(v))
     model.infer_auto_regressive(inp, steps=min(steps, max(1, args.warmup)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -241,6 +241,8 @@ struct FactHandle {
   int sr_rows = 1;       // supervised-rows shortcut of the last cross-modal layer in fact_forward_backward (SrBuf)
   SrBuf sr;
   float* skinny_acc = nullptr;  // zero-filled fp32 accumulator of the skinny-M GEMMs of that layer (caller's stream)
+  float* skinny_acc2 = nullptr; // the same for GEMMs on the side stream (AR sampler: the audio encoder runs there)
+  bool skinny_fwd = false;      // layer_forward hands its GEMMs the accumulator when M <= 512 (fact_infer_ar at small B)
   size_t skinny_floats = 0;
   float* slab = nullptr;  // split-K partial slabs of the wgrad GEMM running on the side stream
   // second stream: wgrad GEMMs run beside the dgrad chain, the audio encoder beside the motion encoder
@@ -470,6 +472,16 @@ void layout_work(FactHandle* h, Bump& b) {
   h->pred = b.take<float>(Mc * h->cfg.out_dim);
   h->scalars = b.take<float>(16);
   h->ar_x16 = b.take<bf16_t>((size_t)B * d);
+  {  // supervised-rows compact buffers, forward half (training: B*T <= B*32 rows; the AR sampler: B rows)
+    SrBuf& r = h->sr;
+    const size_t R = rups((size_t)B * (h->training ? 32 : 1), 64);
+    const int fpc = h->cross.fp;
+    r.rows_max = (int)R;
+    r.a_c = b.take<bf16_t>(R * dp); r.h2_c = b.take<bf16_t>(R * dp); r.pre_c = b.take<bf16_t>(R * fpc);
+    r.g_c = b.take<bf16_t>(R * fpc); r.xf16_c = b.take<bf16_t>(R * dp);
+    r.x_in_c = b.take<float>(R * d); r.x_mid_c = b.take<float>(R * d); r.x_out_c = b.take<float>(R * d);
+    r.mean2_c = b.take<float>(R); r.rstd2_c = b.take<float>(R);
+  }
   if (h->training) {
     int ffmax = h->cross.fp;
     if (h->motion.fp > ffmax) ffmax = h->motion.fp;
@@ -481,17 +493,13 @@ void layout_work(FactHandle* h, Bump& b) {
       if (BH * st->NP * st->dhp > rowmax) rowmax = BH * st->NP * st->dhp;
       if (BH * st->NP > lsemax) lsemax = BH * st->NP;
     }
-    {  // supervised-rows compact buffers: up to 32 target rows per sequence
+    {  // supervised-rows compact buffers, backward half: up to 32 target rows per sequence
       SrBuf& r = h->sr;
-      const size_t R = rups((size_t)B * 32, 64);
+      const size_t R = (size_t)r.rows_max;
       const int fpc = h->cross.fp;
-      r.rows_max = (int)R;
-      r.a_c = b.take<bf16_t>(R * dp); r.h2_c = b.take<bf16_t>(R * dp); r.pre_c = b.take<bf16_t>(R * fpc);
-      r.g_c = b.take<bf16_t>(R * fpc); r.xf16_c = b.take<bf16_t>(R * dp); r.dx16_c = b.take<bf16_t>(R * dp);
+      r.dx16_c = b.take<bf16_t>(R * dp);
       r.dpre_c = b.take<bf16_t>(R * fpc); r.dh2_c = b.take<bf16_t>(R * dp); r.xmid16_c = b.take<bf16_t>(R * dp);
       r.dpred_c = b.take<bf16_t>(R * h->outp);
-      r.x_in_c = b.take<float>(R * d); r.x_mid_c = b.take<float>(R * d); r.x_out_c = b.take<float>(R * d);
-      r.mean2_c = b.take<float>(R); r.rstd2_c = b.take<float>(R);
       r.pred_c = b.take<float>(R * h->cfg.out_dim); r.dx_c = b.take<float>(R * d);
     }
     h->dpred = b.take<bf16_t>(Mc * h->outp);
@@ -681,6 +689,14 @@ void with_skinny(FactHandle* h, GemmParams& g) {
   g.skinny_acc = h->skinny_acc;
   g.skinny_floats = h->skinny_floats;
 }
+// ... and to a GEMM of an ordinary forward layer on stream `s` while the AR sampler runs at small batch: with
+// M = B * n <= 512 rows a GEMM has 3-57 tiles of 128x128 and one workgroup walks all of K (FFN2 at M = 360: 59 us);
+// cut along K over ~256 workgroups it is a few microseconds plus the epilogue pass.
+void with_skinny_fwd(FactHandle* h, GemmParams& g, hipStream_t s) {
+  if (!h->skinny_fwd || g.M > 512 || s == h->aux) return;
+  g.skinny_acc = (s == h->side) ? h->skinny_acc2 : h->skinny_acc;
+  g.skinny_floats = h->skinny_floats;
+}
 
 // dW[Mo][No] += A^T B ; A [K][Mo(lda)], B [K][No(ldb)]
 int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int ldb, int No, int K,
@@ -794,6 +810,7 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
     GemmParams g = gp(a.h1, dp, p.wqkv.t, p.wqkv.ldt, M, 3 * d, d);
     heads_ep(g.ep, st, a.row, 3);
     with_ws(h, g, s);
+    with_skinny_fwd(h, g, s);
     CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
   {
@@ -805,6 +822,7 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
     GemmParams g = gp(a.a, dp, p.wo.t, p.wo.ldt, M, d, d);
     g.ep.out0 = a.x_mid; g.ep.ldo0 = d; g.ep.bias = P(h, p.bo); g.ep.resid = a.x_in; g.ep.ldr = d;
     with_ws(h, g, s);
+    with_skinny_fwd(h, g, s);
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
   {
@@ -816,6 +834,7 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
     GemmParams g = gp(a.h2, dp, p.w1.t, p.w1.ldt, M, st.ff, d);
     g.ep.out0 = a.pre; g.ep.ldo0 = fp; g.ep.out1 = a.g; g.ep.ldo1 = fp; g.ep.bias = P(h, p.b1);
     with_ws(h, g, s);
+    with_skinny_fwd(h, g, s);
     CHK(launch_gemm_nt(EPI_BIAS_GELU, g, s));
   }
   {
@@ -823,6 +842,7 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
     GemmParams g = gp(a.g, fp, p.w2.t, p.w2.ldt, M, d, st.ff);
     g.ep.out0 = a.x_out; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = a.x_mid; g.ep.ldr = d;
     with_ws(h, g, s);
+    with_skinny_fwd(h, g, s);
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
   return 0;
@@ -1412,12 +1432,14 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
     HIPCHK(hipMalloc((void**)&h->sk_cnt[i], kSplitKCounters * sizeof(unsigned)));
     HIPCHK(hipMemset(h->sk_cnt[i], 0, kSplitKCounters * sizeof(unsigned)));
   }
-  if (h->training) {
+  {
     size_t wide = (size_t)h->cross.ff;
     if ((size_t)3 * h->cross.d > wide) wide = (size_t)3 * h->cross.d;
     h->skinny_floats = (size_t)512 * rups(wide, 4);
     HIPCHK(hipMalloc((void**)&h->skinny_acc, h->skinny_floats * sizeof(float)));
     HIPCHK(hipMemset(h->skinny_acc, 0, h->skinny_floats * sizeof(float)));
+    HIPCHK(hipMalloc((void**)&h->skinny_acc2, h->skinny_floats * sizeof(float)));
+    HIPCHK(hipMemset(h->skinny_acc2, 0, h->skinny_floats * sizeof(float)));
   }
   h->ev.resize(1024);  // ~170 records per train step: a stored handle is never re-recorded before its use
   for (hipEvent_t& e : h->ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1443,6 +1465,7 @@ int fact_destroy(FactHandle* h) {
   if (h->aux) (void)hipStreamDestroy(h->aux);
   if (h->lite) (void)hipStreamDestroy(h->lite);
   (void)hipFree(h->skinny_acc);
+  (void)hipFree(h->skinny_acc2);
   (void)hipFree(h->ar_motion);
   for (int i = 0; i < 3; ++i) {
     (void)hipFree(h->sk_slab[i]);
@@ -1848,13 +1871,30 @@ int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, i
   }
   CHK(copy2d(h->ar_motion, ext * sizeof(float), motion_seed, (size_t)mo.n * F * sizeof(float),
              (size_t)mo.n * F * sizeof(float), B, s));
+  // output[:, 0:1, :] is all that survives a step (fact_model.py:128): like the supervised rows of a train step, the
+  // last cross-modal layer runs its attention queries, to_out, LayerNorm 2 and the MLP on that ONE row per sequence
+  // (keys / values still come from all rows), and the head reads the compact rows.
+  const bool sr = h->sr_rows && cr.L >= 1 && cr.n >= 4 && rups((size_t)B, 64) <= (size_t)h->sr.rows_max;
+  struct SkinnyScope {  // split-K GEMMs for the whole model while this call runs at a batch of <= 512 rows per stack
+    FactHandle* h;
+    explicit SkinnyScope(FactHandle* hh, bool on) : h(hh) { h->skinny_fwd = on; }
+    ~SkinnyScope() { h->skinny_fwd = false; }
+  } skinny_scope(h, h->sr_rows != 0);
   for (int i = 0; i < nsteps; ++i) {
     // motion window = frames [i, i+n_m) of the extended track; audio window = frames [i, i+n_a)
     CHK(model_forward_hidden(h, h->ar_motion + (size_t)i * F, ext, audio + (size_t)i * au.feat,
-                             (size_t)audio_len * au.feat, B, s));
-    // output[:, 0:1, :] only (fact_model.py:128): head on token 0 of every sample
-    CHK(launch_pad_cast(cr.out(), 1, (size_t)cr.n * cr.d, B, cr.d, h->ar_x16, cr.d, s));
-    GemmParams g = gp(h->ar_x16, cr.d, h->head.t, h->head.ldt, B, h->cfg.out_dim, cr.d);
+                             (size_t)audio_len * au.feat, B, s, sr ? 1 : 0));
+    const bf16_t* x16 = h->ar_x16;
+    int ldx = cr.d;
+    if (sr) {
+      CHK(launch_pad_cast(h->sr.x_out_c, B, 0, B, cr.d, h->sr.xf16_c, cr.dp, s));
+      x16 = h->sr.xf16_c;
+      ldx = cr.dp;
+    } else {  // head on token 0 of every sample
+      CHK(launch_pad_cast(cr.out(), 1, (size_t)cr.n * cr.d, B, cr.d, h->ar_x16, cr.d, s));
+    }
+    GemmParams g = gp(x16, ldx, h->head.t, h->head.ldt, B, h->cfg.out_dim, cr.d);
+    with_skinny_fwd(h, g, s);
     g.ep.out0 = h->ar_motion + (size_t)(mo.n + i) * F; g.ep.ldo0 = (int)ext; g.ep.bias = P(h, h->head_b);
     CHK(launch_gemm_nt(EPI_F32_BIAS, g, s));
   }
