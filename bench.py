@@ -197,11 +197,11 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(B=4, timed=2):
+def cpu_baseline(B=4, timed=2, budget_s=10.0, max_timed=16):
     """Oracle (PyTorch-CPU fp32 restatement of the reference train step: forward, loss, backward, Keras Adam)
     on a bounded sample of the same workload: fact_v5 at batch 4 (a quarter of the per-GPU batch; the fp32 GEMMs
     of the oracle are large enough at 1440 tokens that frames/s does not depend on the batch), 1 warm-up step
-    + `timed` timed steps on all usable host cores."""
+    + at least `timed` timed steps - as many as fit into `budget_s` seconds - on all usable host cores."""
     from oracle import fact_oracle as O
     cores = min(usable_cores(), 64)
     torch.set_num_threads(cores)
@@ -218,9 +218,11 @@ def cpu_baseline(B=4, timed=2):
         dt, n, note = t_warm, 1, "1 (cold) train step"
     else:
         t0 = time.perf_counter()
-        for i in range(timed):
-            params, m, v = _oracle_step(O, params, m, v, step + 1 + i, cfg, batch)
-        dt, n, note = time.perf_counter() - t0, timed, "1 warm-up + %d timed train steps" % timed
+        n = 0
+        while n < timed or (n < max_timed and time.perf_counter() - t0 < budget_s):
+            params, m, v = _oracle_step(O, params, m, v, step + 1 + n, cfg, batch)
+            n += 1
+        dt, note = time.perf_counter() - t0, "1 warm-up + %d timed train steps" % n
     return {"value": round(n * B * 120 / dt, 2), "unit": "motion frames/sec", "cores": cores, "kind": "port",
             "sample": "%s of fact_v5 at batch %d (%.1f s timed; fp32 PyTorch-CPU oracle, %d threads)" % (
                 note, B, dt, cores)}
