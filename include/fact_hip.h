@@ -143,7 +143,9 @@ int fact_set_step(FactHandle* h, int64_t step);
 
 /* Replaces FACTModel.infer_auto_regressive (fact_model.py:103-132): motion seed (B, n_m, F_m),
  * audio (B, audio_len, F_a) -> out (B, steps_done, out_dim) with row stride `steps` frames;
- * steps_done = min(steps, audio_len - n_a + 1) is returned through *steps_done. */
+ * steps_done = min(steps, audio_len - n_a + 1) is returned through *steps_done.  Everything stays on the device
+ * between frames (no host synchronisation); only row 0 of every step's output is computed past the last layer's
+ * key / value projections (option "sr_rows"). */
 int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, int B, int audio_len,
                   int steps, float* out, int* steps_done, void* stream);
 
@@ -164,6 +166,14 @@ int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* com
  *   "wgrad_slab"     1 = split-K partials as plain stores + a streaming reduce, 0 = fp32 atomics
  *   "side_stream"    1 = wgrad batches / the audio encoder run on the handle's second stream, 0 = one stream
  *   "fuse_adam_cast" 1 = Adam writes the bf16 weight shadows itself, 0 = Adam, then a cast/transpose pass
+ *   "sr_rows"        1 = the last cross-modal layer + head run on the rows that are kept: the B*T supervised rows of a
+ *                        train step (fact_model.py:143-148) and the one generated row per sequence of fact_infer_ar
+ *                        (fact_model.py:128), whose GEMMs of <= 512 rows are then cut along K (fp32 atomics: equal up to
+ *                        summation order, not bit for bit from run to run); 0 = every layer on all rows.  fact_forward is
+ *                        never affected.
+ *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "bwd_splitk", "aux_stream", "adam_hold", "tn_loop",
+ *   "attn_variant", "big_impl", "lite_stream": scheduling / kernel-selection knobs of the A/B runs documented in DESIGN.md
+ *   sections 3 and 6; results are unchanged by them.
  * Unknown keys return an error. */
 int fact_set_option(FactHandle* h, const char* key, int value);
 
