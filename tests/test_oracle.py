@@ -146,3 +146,32 @@ def test_autoregressive_stops_when_audio_runs_out():
     assert out.shape == (2, 1, 225)  # exactly one full 64-frame window
     short = O.infer_auto_regressive(params, cfg, batch["motion_input"], batch["audio_input"][:, :10], steps=5)
     assert short.shape == (2, 0, 225)
+
+
+def test_keras_adam_algebra_against_torch_optim_adam():
+    """The oracle's Keras-Adam restatement against an INDEPENDENT implementation.  Keras applies epsilon to the
+    un-corrected sqrt(v) (`lr_t = lr*sqrt(1-b2^t)/(1-b1^t); p -= lr_t*m/(sqrt(v)+eps)`, the formulation just before
+    section 2.1 of Kingma & Ba), torch.optim.Adam to the bias-corrected one (`p -= lr/(1-b1^t) * m/(sqrt(v)/sqrt(1-b2^t)+eps')`);
+    the two coincide exactly when eps' = eps/sqrt(1-b2^t), which is set per step here.  Checks the update algebra, the moment
+    recursions and the t = step+1 convention over 6 steps in fp64 (what Keras itself does cannot be run here)."""
+    import math
+    g = torch.Generator().manual_seed(11)
+    p0 = {"a": torch.randn(7, 5, generator=g, dtype=torch.float64), "b": torch.randn(9, generator=g, dtype=torch.float64)}
+    grads = [{k: torch.randn(v.shape, generator=g, dtype=torch.float64) * (10.0 ** (-i)) for k, v in p0.items()}
+             for i in range(6)]
+    lr, b1, b2, eps = 3e-3, 0.9, 0.999, 1e-7
+    p = {k: v.clone() for k, v in p0.items()}
+    m = {k: torch.zeros_like(v) for k, v in p0.items()}
+    v = {k: torch.zeros_like(x) for k, x in p0.items()}
+    tp = {k: torch.nn.Parameter(x.clone()) for k, x in p0.items()}
+    opt = torch.optim.Adam(list(tp.values()), lr=lr, betas=(b1, b2), eps=eps)
+    for step, gr in enumerate(grads):
+        p, m, v = O.adam_update(p, gr, m, v, step, lr, b1, b2, eps)
+        for k in tp:
+            tp[k].grad = gr[k].clone()
+        opt.param_groups[0]["eps"] = eps / math.sqrt(1.0 - b2 ** (step + 1))
+        opt.step()
+        for k in tp:
+            assert torch.allclose(p[k], tp[k].detach(), rtol=1e-12, atol=1e-14), (step, k)
+            st = opt.state[tp[k]]
+            assert torch.allclose(m[k], st["exp_avg"], rtol=1e-12, atol=0) and torch.allclose(v[k], st["exp_avg_sq"], rtol=1e-12, atol=0)
