@@ -213,6 +213,9 @@ struct SlotC { static constexpr int value = S; };
 #define BIG_DMA_FIRST 0  // 1 = round-2a order (DMA issues ahead of the fragment reads); A/B build knob
 #endif
 constexpr int DMA_FIRST = BIG_DMA_FIRST;
+#ifndef BIG_DMA_IN_MFMA
+#define BIG_DMA_IN_MFMA 0  // A/B build knob: this many of a wave's LDS-DMA pieces per stage are issued from inside
+#endif                     // its multiply phase (spread between the MFMAs) instead of its read phase
 
 template <class C, bool TN, bool SWAP>
 DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1], const unsigned (&sadv)[C::LPS_LO + 1],
@@ -235,6 +238,25 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
   auto wait_ahead = [&]() {  // at most DIST - 1 later stages of this wave stay in flight
     if (extra) wait_vmcnt<(DIST - 1) * (LPS_LO + 1)>();
     else wait_vmcnt<(DIST - 1) * LPS_LO>();
+  };
+  // BIG_DMA_IN_MFMA: the last PM pieces of a stage are issued during the multiply phase.  Group 0 waits at the end of
+  // that phase (all pieces of stage k+DIST issued: same count as above); group 1 waits at the end of its READ phase,
+  // when only the first LPS - PM pieces of stage k+DIST are out.
+  constexpr int PM = BIG_DMA_IN_MFMA < LPS_LO ? BIG_DMA_IN_MFMA : LPS_LO;
+  auto stage_head = [&](auto slot_c, bool more) {  // pieces [0, LPS_LO - PM) + the extra piece
+    constexpr int SLOT = decltype(slot_c)::value;
+    unsigned char* base = smem + SLOT * STAGE;
+#pragma unroll
+    for (int i = 0; i < LPS_LO - PM; ++i) {
+      glds16(reinterpret_cast<const bf16_t*>(sptr[i] + voff[i]), base + dst[i]);
+      sptr[i] += more ? sadv[i] : 0u;
+    }
+    if (extra) glds16(reinterpret_cast<const bf16_t*>(sptr[LPS_LO] + voff[LPS_LO]), base + dst[LPS_LO]);
+    sptr[LPS_LO] += more ? sadv[LPS_LO] : 0u;
+  };
+  auto wait_ahead_g1 = [&]() {
+    if (extra) wait_vmcnt<(DIST - 2) * (LPS_LO + 1) + (LPS_LO + 1 - PM)>();
+    else wait_vmcnt<(DIST - 2) * LPS_LO + (LPS_LO - PM)>();
   };
 
 #pragma unroll
@@ -297,14 +319,18 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
       for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_nt[SLOT] + i * 1024);
       if constexpr (DMA_FIRST == 0) {
         __builtin_amdgcn_sched_barrier(0);
-        stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
+        if constexpr (PM > 0) stage_head(SlotC<NEXT>{}, kt + DIST + 1 < nk);
+        else stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
       constexpr int SO = (SLOT & 1) * STAGE, PAIR = SLOT / 2;
       bf16x4 blo[NR], bhi[NR], alo[MR], ahi[MR];
       tn_reads<C, SO, PAIR>(ta, tb, alo, ahi, blo, bhi);
-      if constexpr (DMA_FIRST == 0) stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
+      if constexpr (DMA_FIRST == 0) {
+        if constexpr (PM > 0) stage_head(SlotC<NEXT>{}, kt + DIST + 1 < nk);
+        else stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
+      }
       // the asm reads are invisible to hipcc's counters: retire them by hand and pin the order
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -313,14 +339,32 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
 #pragma unroll
       for (int i = 0; i < MR; ++i) af[i] = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
     }
-    if (grp == 1) wait_ahead();
+    if (grp == 1) {
+      if constexpr (PM > 0) wait_ahead_g1();
+      else wait_ahead();
+    }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
-      for (int j = 0; j < NR; ++j)
+      for (int j = 0; j < NR; ++j) {
         acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+        if constexpr (PM > 0) {
+          // piece q of the tail goes out behind MFMA number (q + 1) * MR * NR / (PM + 1)
+          const int t = i * NR + j + 1;
+#pragma unroll
+          for (int q = 0; q < PM; ++q)
+            if (t == (q + 1) * MR * NR / (PM + 1)) {
+              constexpr int SLOTN = NEXT;
+              const int pi = LPS_LO - PM + q;
+              __builtin_amdgcn_sched_barrier(0);
+              glds16(reinterpret_cast<const bf16_t*>(sptr[pi] + voff[pi]), smem + SLOTN * STAGE + dst[pi]);
+              sptr[pi] += (kt + DIST + 1 < nk) ? sadv[pi] : 0u;
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+      }
     __builtin_amdgcn_s_setprio(0);
     if (grp == 0) wait_ahead();
     __builtin_amdgcn_s_barrier();
