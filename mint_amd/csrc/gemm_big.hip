@@ -213,6 +213,9 @@ struct SlotC { static constexpr int value = S; };
 #define BIG_DMA_FIRST 0  // 1 = round-2a order (DMA issues ahead of the fragment reads); A/B build knob
 #endif
 constexpr int DMA_FIRST = BIG_DMA_FIRST;
+#ifndef BIG_PRIO_MODE
+#define BIG_PRIO_MODE 0  // A/B build knob: 0 = s_setprio 1 around every multiply phase (shipped), 1 = no priority changes,
+#endif                   // 2 = static s_setprio 1 for the second-dispatched wave group only, 3 = ... for the first group only
 #ifndef BIG_DMA_IN_MFMA
 #define BIG_DMA_IN_MFMA 0  // A/B build knob: this many of a wave's LDS-DMA pieces per stage are issued from inside
 #endif                     // its multiply phase (spread between the MFMAs) instead of its read phase
@@ -344,7 +347,7 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
       else wait_ahead();
     }
     __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (BIG_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -365,10 +368,15 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
             }
         }
       }
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (BIG_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);
     if (grp == 0) wait_ahead();
     __builtin_amdgcn_s_barrier();
   };
+  if constexpr (BIG_PRIO_MODE == 2) {
+    if (grp == 1) __builtin_amdgcn_s_setprio(1);
+  } else if constexpr (BIG_PRIO_MODE == 3) {
+    if (grp == 0) __builtin_amdgcn_s_setprio(1);
+  }
   if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one phase behind group 0
   for (int kt = 0; kt < nk; kt += NST) {
     body(SlotC<0>{}, kt);
@@ -378,6 +386,7 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
       if (kt + 3 < nk) body(SlotC<3>{}, kt + 3);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
+  if constexpr (BIG_PRIO_MODE >= 2) __builtin_amdgcn_s_setprio(0);
   wait_vmcnt<0>();  // the run-ahead stages past the end of K: landed before the ring is reused for staging
   __builtin_amdgcn_s_barrier();
 }
