@@ -1,0 +1,58 @@
+"""bench.py's FLOP accounting against an independent count from the shipped model dimensions (SURVEY section 8d:
+80.97 GFLOP forward per sample = linear 75.35 + attention 5.44 + embed / head 0.19; train step = 3x = 242.92 GFLOP per
+sample = 2.024 GFLOP per motion frame), and the share the supervised-rows shortcut does not execute."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)   # main() only runs under __main__
+    return mod
+
+
+D, FF, H, OUT = 800, 3072, 10, 225
+STACKS = {"motion": (120, 2, 225), "audio": (240, 2, 35), "cross": (360, 12, None)}
+
+
+def _forward_flops():
+    linear = attention = 0.0
+    for n, layers, _ in STACKS.values():
+        linear += layers * 2.0 * n * (D * 3 * D + D * D + 2 * D * FF)
+        attention += layers * 4.0 * n * n * D          # QK^T and PV, all heads
+    embed_head = sum(2.0 * n * f * D for n, _, f in STACKS.values() if f) + 2.0 * 360 * D * OUT
+    return linear, attention, embed_head
+
+
+def test_flops_per_sample_and_frame(bench):
+    linear, attention, embed_head = _forward_flops()
+    assert linear / 1e9 == pytest.approx(75.35, abs=0.01)
+    assert attention / 1e9 == pytest.approx(5.44, abs=0.01)
+    assert embed_head / 1e9 == pytest.approx(0.19, abs=0.01)
+    fwd = linear + attention + embed_head
+    assert fwd / 1e9 == pytest.approx(80.97, abs=0.02)
+    assert 3 * fwd / 120 == pytest.approx(bench.FLOP_PER_FRAME, rel=1e-3)
+    assert bench.BATCH_PER_GPU == 16 and bench.TARGET_LEN == 20 and bench.PEAK_BF16_TFLOPS == 2500.0
+    # headline arithmetic: frames/s at 100 % of the bf16 roofline (1.235 M frames/s per GPU)
+    assert bench.PEAK_BF16_TFLOPS * 1e12 / bench.FLOP_PER_FRAME == pytest.approx(1.235e6, rel=2e-3)
+
+
+def test_executed_fraction_of_the_supervised_rows_shortcut(bench):
+    # last cross-modal layer: queries / to_out / MLP / head on 20 of 360 rows; LN1 + QKV stay on all rows
+    n, t = 360, 20
+    skipped = (n - t) * (2.0 * D * D + 4.0 * D * FF + 4.0 * n * D + 2.0 * D * OUT)
+    total = 3 * sum(_forward_flops())
+    assert bench.executed_flop_fraction() == pytest.approx(1.0 - 3 * skipped / total, rel=1e-4)
+    assert bench.executed_flop_fraction() == pytest.approx(0.947, abs=1e-3)
+    assert bench.executed_flop_fraction(target_len=360) == pytest.approx(1.0)
+
+
+def test_kernel_symbol_table_names_the_classes_the_engine_times(bench):
+    for cls in ("wgrad_group", "attention_fwd", "attention_bwd", "ffn1+gelu", "adam+shadows", "ln_bwd_dx"):
+        assert cls in bench.KERNEL_SYMBOLS
