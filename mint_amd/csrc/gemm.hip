@@ -907,6 +907,7 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
     int cfg = -1, old_mr = 0;
     if (variant >= 10 && variant <= 12) cfg = variant - 10;
     else if (variant == 14) cfg = BIG_256x128;
+    else if (variant == 15) cfg = BIG_288x256_W12;  // experimental 12-wave three-group loop (tests / bench only)
     else if (variant == 6) old_mr = 9;
     else if (variant == 7) old_mr = 8;
     else if (variant == 0) {
