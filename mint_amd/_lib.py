@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfact_hip.so")
+# FACT_LIB: a development build of the SAME library (tools/build_variant.sh, same-box A/B of kernel variants); the shipped
+# in-tree library otherwise.  Either way a missing file is an error, never a fallback.
+LIB_PATH = os.environ.get("FACT_LIB") or os.path.join(_HERE, "lib", "libfact_hip.so")
 
 # epilogue kinds (mint_amd/csrc/gemm.h)
 EPI_BF16, EPI_F32_BIAS, EPI_F32_BIAS_POS, EPI_F32_BIAS_RESID = 0, 1, 2, 3
