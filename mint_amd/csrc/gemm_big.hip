@@ -66,7 +66,7 @@ struct BigCfg {
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
   static constexpr int NW = WGM * WGN;  // 8 waves (two groups half a K step apart) or 12 (three groups, big_mainloop3)
   static constexpr int LPS_LO = NPIECE / NW, EXTRA = NPIECE % NW;  // waves < EXTRA issue one more piece
-  static_assert(NW == 8 || (NW == 12 && WGN == 4 && NSTAGE_ == 4), "8 waves, or 12 as 3 x 4 with a 4-slot ring");
+  static_assert(NW == 8 || (NW == 12 && NSTAGE_ == 4), "8 waves, or 12 (three groups of four) with a 4-slot ring");
   static_assert(NSTAGE >= 3 && NSTAGE <= 6, "ring depth");
   static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS");
 };
@@ -1148,6 +1148,7 @@ using Cfg160x256r6 = BigCfg<2, 5, 4, 4, 6>;  // 6-slot LDS-DMA ring (160 KiB) fo
 // GELU math, staging, 35-70 MB of stores for the K = 800 GEMMs) runs under the main loop of the other
 using Cfg256x128 = BigCfg<4, 4, 2, 4, 3, 2>;
 using Cfg288x256w12 = BigCfg<3, 6, 4, 4>;  // experimental: 12 waves, three rotating groups (big_mainloop3)
+using Cfg288x160w12 = BigCfg<6, 3, 2, 5>;  // ... for the N = 800 outputs (48x80 wave tiles)
 
 template <int EPI>
 int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
@@ -1158,6 +1159,7 @@ int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
     case BIG_256x128: return launch_big_nt_cfg<Cfg256x128, EPI>(p, s);
 #ifdef FACT_EXPERIMENTAL_W12  // FACT_EXTRA_FLAGS=-DFACT_EXPERIMENTAL_W12 ./build.sh ; tools/bench_r2.py w12
     case BIG_288x256_W12: return launch_big_nt_cfg<Cfg288x256w12, EPI>(p, s);
+    case BIG_288x160_W12: return launch_big_nt_cfg<Cfg288x160w12, EPI>(p, s);
 #endif
   }
   return -7;
@@ -1175,6 +1177,7 @@ int big_tile_dims(int cfg, int* bm, int* bn) {
     case BIG_160x256: *bm = 160; *bn = 256; return 0;
     case BIG_256x128: *bm = 256; *bn = 128; return 0;
     case BIG_288x256_W12: *bm = 288; *bn = 256; return 0;
+    case BIG_288x160_W12: *bm = 288; *bn = 160; return 0;
   }
   return -1;
 }

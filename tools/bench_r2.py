@@ -154,7 +154,10 @@ if __name__ == "__main__":
         nt_case(5760, 3072, 800, L.EPI_GELU_BWD, [10, 15], "dgrad gelu'")
         nt_case(5760, 2400, 800, L.EPI_BF16, [11, 10, 15], "QKV (plain)")
         nt_case(5760, 3072, 3072, L.EPI_BF16, [10, 15], "long K")
-        nt_case(5760, 800, 3072, L.EPI_F32_BIAS_RESID, [12, 15], "FFN2+resid")
+        nt_case(5760, 800, 3072, L.EPI_F32_BIAS_RESID, [12, 16], "FFN2+resid")   # 16 = 288x160 on 12 waves
+        nt_case(5760, 800, 3072, L.EPI_BF16, [12, 16], "dgrad FFN1")
+        nt_case(5760, 800, 800, L.EPI_F32_BIAS_RESID, [14, 12, 16], "out-proj+resid")
+        nt_case(300, 800, 96, L.EPI_BF16, [12, 16], "parity N800")
         nt_case(8192, 8192, 8192, L.EPI_BF16, [11, 10, 15], "8192^3")
     if what == "small":
         for Me in (5760, 3840, 1920):
