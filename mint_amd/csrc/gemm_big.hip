@@ -549,7 +549,7 @@ DEVINL void tn_mainloop_pf(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
 //             issue is group 0's A(j) = slot 3j-2.
 // Prefetch distance is two K steps (>= 4 slots between the last issue of a stage and its first read).
 // -------------------------------------------------------------------------------------------------
-template <class C, bool SWAP>
+template <class C, bool TN, bool SWAP>
 DEVINL void big_mainloop3(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1], const unsigned (&sadv)[C::LPS_LO + 1],
                           const unsigned (&voff)[C::LPS_LO + 1], const int (&dst)[C::LPS_LO + 1], int nk, int wave,
                           int wm, int wn, int lane, f32x4 (&acc)[C::MR][C::NR]) {
@@ -579,14 +579,31 @@ DEVINL void big_mainloop3(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1
 #pragma unroll
     for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  unsigned a_nt[NST], b_nt[NST];
-  {
+  unsigned a_nt[NST], b_nt[NST];                          // NT: per ring slot, + i * 1024 immediates
+  unsigned ta[MR][(NST + 1) / 2], tb[NR][(NST + 1) / 2];  // TN: per unit and slot pair {0,1} / {2,3}, + immediates
+  if constexpr (!TN) {
     const int r = lane & 15, chunk = lane >> 4;
     const unsigned lanepart = (unsigned)(r * 64 + ((chunk ^ ring_g(r)) << 4));
 #pragma unroll
     for (int sl = 0; sl < NST; ++sl) {
       a_nt[sl] = (unsigned)(sl * STAGE + wm * MR * 1024) + lanepart;
       b_nt[sl] = (unsigned)(sl * STAGE + C::A_BYTES + wn * NR * 1024) + lanepart;
+    }
+  } else {
+    const unsigned l0 = lds_addr(smem);
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+      unsigned off, dh;
+      TnImg<C::BM>::frag_off(TnImg<C::BM>::template unit_of<C::WGM, MR>(wm, i), lane, off, dh);
+      ta[i][0] = l0 + off;
+      ta[i][1] = l0 + off + 2 * STAGE;
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      unsigned off, dh;
+      TnImg<C::BN>::frag_off(TnImg<C::BN>::template unit_of<C::WGN, NR>(wn, j), lane, off, dh);
+      tb[j][0] = l0 + C::A_BYTES + off;
+      tb[j][1] = l0 + C::A_BYTES + off + 2 * STAGE;
     }
   }
 
@@ -606,11 +623,24 @@ DEVINL void big_mainloop3(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     // B(kt)
+    if constexpr (!TN) {
 #pragma unroll
-    for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + b_nt[SLOT] + j * 1024);
+      for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + b_nt[SLOT] + j * 1024);
 #pragma unroll
-    for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_nt[SLOT] + i * 1024);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_nt[SLOT] + i * 1024);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else {
+      constexpr int SO = (SLOT & 1) * STAGE, PAIR = SLOT / 2;
+      bf16x4 blo[NR], bhi[NR], alo[MR], ahi[MR];
+      tn_reads<C, SO, PAIR>(ta, tb, alo, ahi, blo, bhi);
+      // the asm reads are invisible to hipcc's counters: retire them by hand and pin the order
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NR; ++j) bfr[j] = __builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) af[i] = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+    }
     if (grp == 2) wait_stages_left(SlotC<1>{});
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -715,7 +745,7 @@ __global__ __launch_bounds__(C::NW * 64, (C::NW / 4) * C::WGS_PER_CU) void big_n
     }
   }
   f32x4 acc[MR][NR];
-  if constexpr (C::NW == 12) big_mainloop3<C, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+  if constexpr (C::NW == 12) big_mainloop3<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
   else big_mainloop<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
 
   if (p.splitk > 1) {
@@ -991,7 +1021,7 @@ DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f
 // an XCD owns form a near-square patch (5 x 5 operand panels per K step instead of 24 + 24).
 // -------------------------------------------------------------------------------------------------
 template <class C, int PF>
-__global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
+__global__ __launch_bounds__(C::NW * 64, C::NW == 12 ? 3 : 1) void big_tn_kernel(const TnGroup g) {
   constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1018,7 +1048,7 @@ __global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
   int dst[C::LPS_LO + 1];
 #pragma unroll
   for (int i = 0; i < C::LPS_LO + 1; ++i) {
-    const int q = (i < C::LPS_LO) ? wave * C::LPS_LO + i : 8 * C::LPS_LO + wave;
+    const int q = (i < C::LPS_LO) ? wave * C::LPS_LO + i : C::NW * C::LPS_LO + wave;
     const int qq = min(q, C::NPIECE - 1);
     int k, col;
     if (qq < C::A_PIECES) {  // wave-uniform
@@ -1042,6 +1072,51 @@ __global__ __launch_bounds__(512, 1) void big_tn_kernel(const TnGroup g) {
   for (int i = 0; i < MR; ++i) mrow[i] = m0 + TnImg<BM>::template unit_of<C::WGM, MR>(wm, i) * 16;
 #pragma unroll
   for (int j = 0; j < NR; ++j) ncol[j] = n0 + TnImg<BN>::template unit_of<C::WGN, NR>(wn, j) * 16;
+  if constexpr (C::NW == 12) {
+    // experimental three-group loop: <= 168 VGPRs, so the read-modify-write of the gradient goes one tile row at a time
+    if (!pr.trans_out) {
+      big_mainloop3<C, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int m = mrow[i] + (lane & 15);
+        float4 old[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const int n = ncol[j] + (lane >> 4) * 4;
+          old[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (m < pr.M && n + 3 < pr.N) old[j] = *reinterpret_cast<const float4*>(pr.out + (size_t)m * pr.ldo + n);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const int n = ncol[j] + (lane >> 4) * 4;
+          if (m < pr.M && n + 3 < pr.N)
+            *reinterpret_cast<float4*>(pr.out + (size_t)m * pr.ldo + n) =
+                make_float4(old[j].x + acc[i][j][0], old[j].y + acc[i][j][1], old[j].z + acc[i][j][2], old[j].w + acc[i][j][3]);
+        }
+      }
+    } else {
+      big_mainloop3<C, true, false>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int m = mrow[i] + (lane >> 4) * 4;
+        float4 old[NR];
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const int n = ncol[j] + (lane & 15);
+          old[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (n < pr.N && m + 3 < pr.M) old[j] = *reinterpret_cast<const float4*>(pr.out + (size_t)n * pr.ldo + m);
+        }
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          const int n = ncol[j] + (lane & 15);
+          if (n < pr.N && m + 3 < pr.M)
+            *reinterpret_cast<float4*>(pr.out + (size_t)n * pr.ldo + m) =
+                make_float4(old[j].x + acc[i][j][0], old[j].y + acc[i][j][1], old[j].z + acc[i][j][2], old[j].w + acc[i][j][3]);
+        }
+      }
+    }
+    return;
+  }
   if (!pr.trans_out) {
     if constexpr (PF) tn_mainloop_pf<C, true, PF >= 2, (PF > 2 ? PF - 2 : 0)>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
     else big_mainloop<C, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
@@ -1149,6 +1224,7 @@ using Cfg160x256r6 = BigCfg<2, 5, 4, 4, 6>;  // 6-slot LDS-DMA ring (160 KiB) fo
 using Cfg256x128 = BigCfg<4, 4, 2, 4, 3, 2>;
 using Cfg288x256w12 = BigCfg<3, 6, 4, 4>;  // experimental: 12 waves, three rotating groups (big_mainloop3)
 using Cfg288x160w12 = BigCfg<6, 3, 2, 5>;  // ... for the N = 800 outputs (48x80 wave tiles)
+using Cfg160x384w12 = BigCfg<2, 5, 6, 4>;  // ... grouped TN (weight gradients): 80x64 wave tiles, 130 tiles per cross layer
 
 template <int EPI>
 int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
@@ -1247,7 +1323,7 @@ int launch_big_tn_group_t(TnGroup g, hipStream_t s, int parts) {
     const int lo = (int)((long long)total * i / parts), hi = (int)((long long)total * (i + 1) / parts);
     if (hi <= lo) continue;
     g.tile0 = lo;
-    hipLaunchKernelGGL((big_tn_kernel<C, PF>), dim3(hi - lo), dim3(512), C::LDS_BYTES, s, g);
+    hipLaunchKernelGGL((big_tn_kernel<C, PF>), dim3(hi - lo), dim3(C::NW * 64), C::LDS_BYTES, s, g);
   }
   return 0;
 }
@@ -1258,6 +1334,9 @@ int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
   if (g_tn_cfg == 1) return launch_big_tn_group_t<Cfg160x256, 1>(g, s, parts);
   if (g_tn_cfg == 2) return launch_big_tn_group_t<Cfg160x256, 2>(g, s, parts);
   if (g_tn_cfg == 6) return launch_big_tn_group_t<Cfg160x256r6, 2>(g, s, parts);  // interleaved loop, 6-slot ring
+#ifdef FACT_EXPERIMENTAL_W12
+  if (g_tn_cfg == 12) return launch_big_tn_group_t<Cfg160x384w12, 0>(g, s, parts);  // 12 waves, three rotating groups
+#endif
 #ifdef BIG_ABLATION
   if (g_tn_cfg == 3) return launch_big_tn_group_t<Cfg160x256, 3>(g, s, parts);  // interleaved loop without DMA
   if (g_tn_cfg == 4) return launch_big_tn_group_t<Cfg160x256, 4>(g, s, parts);  // ... without MFMAs

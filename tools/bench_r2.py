@@ -120,8 +120,9 @@ def wgrad_layer(K, d=800, ff=3072):
             o.zero_()
         new()
         torch.cuda.synchronize()
-        ref = [xin[:, :d].float().t() @ gact.float()] if False else None
-        e = ((outs_new[1] - (h2[:, :d].float().t() @ dpre.float())).norm() / outs_new[1].norm()).item()
+        refs = [gact[:, :ff].float().t() @ xin[:, :d].float(), h2[:, :d].float().t() @ dpre[:, :ff].float(),
+                att[:, :d].float().t() @ xmid[:, :d].float(), h1[:, :d].float().t() @ dqkv[:, :3 * d].float()]
+        e = max(((o - r).norm() / r.norm()).item() for o, r in zip(outs_new, refs))  # all four gradients of the group
         line += " | loop%d %6.1f us %4.0f TF err %.1e" % (cfg, time_us(new), flops / time_us(new) / 1e6, e)
     lib.fact_debug_gemm_tn_cfg(0)
     print("wgrad layer K%5d: round-1 %6.1f us %4.0f TF%s" % (K, t_old, flops / t_old / 1e6, line), flush=True)
