@@ -104,8 +104,16 @@ def gemm_path(request):
     L.lib().fact_debug_force_generic_gemm(0)
 
 
-@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14],
-                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160", "big256x128x2"])
+# FACT_EXPERIMENTAL_W12=1 (with FACT_LIB pointing at a library built with -DFACT_EXPERIMENTAL_W12, tools/build_variant.sh)
+# adds the not-yet-shipped 12-wave three-group kernels to the kernel-choice fixtures below; the default suite does not
+# contain them.
+import os  # noqa: E402
+_EXP_W12 = os.environ.get("FACT_EXPERIMENTAL_W12") == "1"
+
+
+@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14] + ([15, 16] if _EXP_W12 else []),
+                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160", "big256x128x2"]
+                + (["w12-288x256", "w12-288x160"] if _EXP_W12 else []))
 def nt_variant(request):
     """NT kernel choice: the engine's automatic pick, the 128x128 kernel, the round-1 big-tile kernels and
     every tile config of the big-tile family (gemm_big.hip), forced regardless of the tile-count heuristic."""
@@ -258,8 +266,16 @@ def _tn_group(probs, K):
     _sync()
 
 
+@pytest.fixture(params=[0] + ([12] if _EXP_W12 else []), ids=["staggered"] + (["w12-160x384"] if _EXP_W12 else []))
+def tn_group_loop(request):
+    """main loop / tile config of the grouped wgrad kernel (engine option tn_loop)"""
+    L.lib().fact_debug_gemm_tn_cfg(request.param)
+    yield request.param
+    L.lib().fact_debug_gemm_tn_cfg(0)
+
+
 @pytest.mark.parametrize("K", [32, 96, 1440, 5760])
-def test_gemm_tn_group(K):
+def test_gemm_tn_group(tn_group_loop, K):
     """Grouped whole-K wgrad kernel: the four weight-gradient shapes of a FACT layer in one launch (dW2 stored
     transposed), ragged column counts (2400 = 9.4 tiles of 256, 800 = 3.1), accumulation into existing values."""
     g = torch.Generator(device=DEV).manual_seed(31)
@@ -283,7 +299,7 @@ def test_gemm_tn_group(K):
     _close(oq, 2.0 + h1[:, :d].float().t() @ dqkv[:, :3 * d].float(), 1e-3, tol, "dWqkv")
 
 
-def test_gemm_tn_group_small_dims():
+def test_gemm_tn_group_small_dims(tn_group_loop):
     """Other hidden sizes: d = 128 (one partial 160-row tile), d = 1536 (9.6 tiles), single problem."""
     g = torch.Generator(device=DEV).manual_seed(32)
     for (K, Mo, No) in [(64, 128, 512), (256, 1536, 384), (128, 160, 256), (96, 164, 260)]:
