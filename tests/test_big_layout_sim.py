@@ -40,7 +40,7 @@ class TnImg:
         return self.N128 * 8192 + (g * 8 + (s >> 2)) * 64 + ((u ^ (g & 1)) << 5) + (s & 3) * 8, 4 * 64
 
 
-@pytest.mark.parametrize("W", [160, 256, 128, 32])
+@pytest.mark.parametrize("W", [160, 256, 128, 32, 384])   # 384: the experimental 160x384 grouped-TN tile
 def test_tn_image_fragments_and_banks(W):
     img = TnImg(W)
     # operand tile A[k][m] = k * 1000 + m (exact in int32); LDS image as 2-byte elements
@@ -107,26 +107,62 @@ def test_nt_ring_image(rows):
             assert len({(addrs[l] // 16) % 16 for l in g}) == 16
 
 
-CFGS = {"288x256": (2, 9, 4, 4), "256x256": (2, 8, 4, 4), "256x160": (4, 4, 2, 5), "160x256": (2, 5, 4, 4)}
+CFGS = {"288x256": (2, 9, 4, 4), "256x256": (2, 8, 4, 4), "256x160": (4, 4, 2, 5), "160x256": (2, 5, 4, 4),
+        # experimental 12-wave configs (big_mainloop3, -DFACT_EXPERIMENTAL_W12)
+        "w12-288x256": (3, 6, 4, 4), "w12-288x160": (6, 3, 2, 5), "w12-160x384": (2, 5, 6, 4)}
 
 
-def pick_ch(MR, regions_bytes_per_rowtile, lds_bytes, nout=1):
+def pick_ch(MR, regions_bytes_per_rowtile, lds_bytes, nout=1, nw=8):
     for div in (1, 2, 3, 4):
-        if MR % div == 0 and 8 * nout * (MR // div) * regions_bytes_per_rowtile <= lds_bytes:
+        if MR % div == 0 and nw * nout * (MR // div) * regions_bytes_per_rowtile <= lds_bytes:
             return MR // div
     return 1
 
 
-@pytest.mark.parametrize("name", ["288x256", "256x256", "256x160"])
+@pytest.mark.parametrize("name", ["w12-288x256", "w12-288x160", "w12-160x384", "288x256", "160x256"])
+def test_dma_pieces_cover_a_stage_once(name):
+    """wave w issues pieces w*LPS .. and, for w < EXTRA, piece NW*LPS + w (BigCfg): every 1 KiB piece of a stage exactly once"""
+    WGM, MR, WGN, NR = CFGS[name]
+    nw, npiece = WGM * WGN, WGM * MR + WGN * NR
+    lps, extra = npiece // nw, npiece % nw
+    issued = []
+    for w in range(nw):
+        issued += [w * lps + i for i in range(lps)]
+        if w < extra:
+            issued.append(nw * lps + w)
+    assert sorted(issued) == list(range(npiece))
+    assert 4 * npiece * 1024 <= 160 * 1024            # 4-slot ring fits the LDS
+    if nw == 12:                                      # three groups of four consecutive waves; <= 170 VGPRs per wave
+        assert 4 * MR * NR + 4 * (MR + NR) <= 150
+
+
+@pytest.mark.parametrize("name,side", [("w12-160x384", "A"), ("w12-160x384", "B"), ("160x256", "A"), ("160x256", "B")])
+def test_tn_unit_split_covers_the_operand(name, side):
+    """TnImg::unit_of: the 16-column units of an operand are dealt to the waves along it so that every unit is owned by
+    exactly one wave index and the main / tail split is the same for every wave (compile-time hh increments)."""
+    WGM, MR, WGN, NR = CFGS[name]
+    W, WG, R = (WGM * MR * 16, WGM, MR) if side == "A" else (WGN * NR * 16, WGN, NR)
+    n128, tail = W // 128, (W % 128) // 32
+    main, tailp = 8 * n128 // WG, R - 8 * n128 // WG
+    assert (8 * n128) % WG == 0 and tailp * WG == 2 * tail
+    units = []
+    for w in range(WG):
+        for i in range(R):
+            units.append(w * main + i if i < main else 8 * n128 + w * tailp + (i - main))
+    assert sorted(units) == list(range(W // 16))
+
+
+@pytest.mark.parametrize("name", ["288x256", "256x256", "256x160", "w12-288x256", "w12-288x160"])
 @pytest.mark.parametrize("esize,nout", [(2, 1), (2, 2), (4, 1)])
 def test_staged_epilogue_maps(name, esize, nout):
     WGM, MR, WGN, NR = CFGS[name]
+    nw = WGM * WGN
     lds_bytes = 4 * ((WGM * MR + WGN * NR) * 1024)
     ROWB = NR * 16 * esize
     STR, CPR = ROWB + 16, ROWB // 16
-    CH = pick_ch(MR, 16 * STR, lds_bytes, nout)
+    CH = pick_ch(MR, 16 * STR, lds_bytes, nout, nw)
     REG = CH * 16 * STR
-    assert 8 * nout * REG <= lds_bytes and MR % CH == 0
+    assert nw * nout * REG <= lds_bytes and MR % CH == 0
     TOT = CH * 16 * CPR
     IT = (TOT + 63) // 64
     per = 16 // esize  # elements per 16-byte chunk
