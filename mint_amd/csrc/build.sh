@@ -6,6 +6,12 @@ OUT=../lib
 mkdir -p "$OUT" "$OUT/obj"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $FACT_EXTRA_FLAGS"
+# the flag set is part of the object cache key: a default build after a variant build (FACT_EXTRA_FLAGS=-D...) must not
+# link the variant's objects into the shipped library, nor the other way round
+if [ "$(cat "$OUT/obj/.flags" 2>/dev/null)" != "$FLAGS" ]; then
+  rm -f "$OUT"/obj/*.o
+  echo "$FLAGS" > "$OUT/obj/.flags"
+fi
 pids=()
 for f in gemm gemm_big rowops attention engine probe; do
   if [ ! -f "$OUT/obj/$f.o" ] || [ "$f.hip" -nt "$OUT/obj/$f.o" ] || [ -n "$(find . ../../include -name '*.h' -newer "$OUT/obj/$f.o" 2>/dev/null)" ]; then

@@ -1313,18 +1313,20 @@ int fact_abi_version(void) { return FACT_ABI_VERSION; }
 
 unsigned int fact_crc32c(const void* data, size_t n, unsigned int crc) {
   // slicing-by-8, tables built on first use (reflected polynomial 0x82F63B78)
-  static uint32_t T[8][256];
-  static bool ready = false;
-  if (!ready) {
+  // (function-local static initialised by a lambda: thread-safe - the input prefetch thread and checkpoint code both call in)
+  struct Tables { uint32_t t[8][256]; };
+  static const Tables tables = [] {
+    Tables r;
     for (uint32_t i = 0; i < 256; ++i) {
       uint32_t c = i;
       for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
-      T[0][i] = c;
+      r.t[0][i] = c;
     }
     for (uint32_t i = 0; i < 256; ++i)
-      for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xff];
-    ready = true;
-  }
+      for (int t = 1; t < 8; ++t) r.t[t][i] = (r.t[t - 1][i] >> 8) ^ r.t[0][r.t[t - 1][i] & 0xff];
+    return r;
+  }();
+  const uint32_t (*T)[256] = tables.t;
   const unsigned char* p = (const unsigned char*)data;
   uint32_t c = ~crc;
   while (n >= 8) {

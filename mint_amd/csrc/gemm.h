@@ -67,8 +67,7 @@ constexpr size_t kSplitKSlabBytes = (size_t)256 * 288 * 256 * 4;  // 256 workgro
 constexpr int kSplitKCounters = 1024;
 
 // ---- big-tile family (gemm_big.hip): one 8-wave workgroup per CU, 4-deep LDS-DMA ring -------------------
-enum BigCfgId : int { BIG_288x256 = 0, BIG_256x256 = 1, BIG_256x160 = 2, BIG_160x256 = 3, BIG_256x128 = 4,
-                      BIG_288x256_W12 = 5, BIG_288x160_W12 = 6 /* experimental 12-wave three-group loop (gemm_big.hip big_mainloop3) */ };
+enum BigCfgId : int { BIG_288x256 = 0, BIG_256x256 = 1, BIG_256x160 = 2, BIG_160x256 = 3, BIG_256x128 = 4 };
 int big_tile_dims(int cfg, int* bm, int* bn);
 // NT GEMM on a given tile config (K % 32 == 0, splitk == 1); fused epilogues as above.
 int launch_big_nt(int cfg, int epi, const GemmParams& p, hipStream_t stream);

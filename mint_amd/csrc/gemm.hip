@@ -907,8 +907,6 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
     int cfg = -1, old_mr = 0;
     if (variant >= 10 && variant <= 12) cfg = variant - 10;
     else if (variant == 14) cfg = BIG_256x128;
-    else if (variant == 15) cfg = BIG_288x256_W12;  // experimental 12-wave three-group loop (tests / bench only)
-    else if (variant == 16) cfg = BIG_288x160_W12;
     else if (variant == 6) old_mr = 9;
     else if (variant == 7) old_mr = 8;
     else if (variant == 0) {
@@ -935,11 +933,10 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
         cfg = BIG_256x128;
       }
     }
-    if ((cfg == BIG_256x160 || cfg == BIG_288x160_W12) && ws) {
+    if (cfg == BIG_256x160 && ws) {
       // N = 800 outputs give only 5 column tiles: M = 5760 -> 115 tiles on 256 CUs.  With a workspace each
       // tile is cut along K into 2-4 slices (<= 256 workgroups) that finish in-kernel.
-      const int rows160 = (cfg == BIG_256x160) ? 256 : 288;
-      const int t160 = ((p.N + 159) / 160) * ((p.M + rows160 - 1) / rows160);
+      const int t160 = ((p.N + 159) / 160) * ((p.M + 255) / 256);
       int sk = 256 / t160;
       if (sk > g_splitk_max) sk = g_splitk_max;
       // the finish moves 2 x the fp32 tile through L2/fabric (~10 us at 230 workgroups, round-2 bench): it

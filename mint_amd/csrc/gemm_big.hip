@@ -64,9 +64,9 @@ struct BigCfg {
   static constexpr int NPIECE = A_PIECES + B_PIECES;
   static constexpr int STAGE_BYTES = NPIECE * 1024;
   static constexpr int LDS_BYTES = NSTAGE * STAGE_BYTES;
-  static constexpr int NW = WGM * WGN;  // 8 waves (two groups half a K step apart) or 12 (three groups, big_mainloop3)
+  static constexpr int NW = WGM * WGN;  // 8 waves: two groups half a K step apart
   static constexpr int LPS_LO = NPIECE / NW, EXTRA = NPIECE % NW;  // waves < EXTRA issue one more piece
-  static_assert(NW == 8 || (NW == 12 && NSTAGE_ == 4), "8 waves, or 12 (three groups of four) with a 4-slot ring");
+  static_assert(NW == 8, "8 waves");
   static_assert(NSTAGE >= 3 && NSTAGE <= 6, "ring depth");
   static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS");
 };
@@ -533,144 +533,6 @@ DEVINL void tn_mainloop_pf(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
   __builtin_amdgcn_s_barrier();
 }
 
-// -------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (round 2, written without GPU time left; selected only by nt_variant 15 / BIG_288x256_W12, not used by
-// the engine): the same 288x256 tile on TWELVE waves = three groups of four (one wave of each group per SIMD, 96x64 wave
-// tile = 24 MFMAs and 96 accumulators, <= 168 VGPRs), rotating through three slots per K step:
-//     A(j): issue this wave's LDS-DMA pieces of stage j+2      (the phase whose issue cost dominates the 8-wave loop)
-//     B(j): read the fragments of stage j                      (10 ds_read_b128)
-//     C(j): multiply step j                                    (24 MFMAs = 384 cycles of matrix pipe)
-// Group g runs g slots behind group 0, one s_barrier per slot, so in every slot one wave of a SIMD multiplies while its
-// two partners issue DMA / read fragments: the matrix pipe waits for max(A, B, C) instead of for A + B.
-//   landing:  stage j is first read by group 0 in B(j) = global slot 3j-1; every wave retires its own pieces of stage j
-//             before the barrier that ends slot 3j-2: group 0 at the end of A(j) (stages j+1, j+2 may stay in flight),
-//             group 1 at the end of C(j-1) and group 2 at the end of B(j-1) (stage j+1 may stay in flight).
-//   re-use:   stage j+2 overwrites the ring slot of stage j-2, last read by group 2 in B(j-2) = slot 3j-5; the earliest
-//             issue is group 0's A(j) = slot 3j-2.
-// Prefetch distance is two K steps (>= 4 slots between the last issue of a stage and its first read).
-// -------------------------------------------------------------------------------------------------
-template <class C, bool TN, bool SWAP>
-DEVINL void big_mainloop3(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1], const unsigned (&sadv)[C::LPS_LO + 1],
-                          const unsigned (&voff)[C::LPS_LO + 1], const int (&dst)[C::LPS_LO + 1], int nk, int wave,
-                          int wm, int wn, int lane, f32x4 (&acc)[C::MR][C::NR]) {
-  constexpr int MR = C::MR, NR = C::NR, NST = C::NSTAGE, STAGE = C::STAGE_BYTES;
-  constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
-  static_assert(NST == 4 && C::NW == 12, "three groups on a 4-slot ring");
-  const int grp = wave >> 2;
-  const bool extra = EXTRA && wave < EXTRA;
-
-  auto stage = [&](auto slot_c, bool more) {
-    constexpr int SLOT = decltype(slot_c)::value;
-    unsigned char* base = smem + SLOT * STAGE;
-#pragma unroll
-    for (int i = 0; i < LPS_LO; ++i) glds16(reinterpret_cast<const bf16_t*>(sptr[i] + voff[i]), base + dst[i]);
-    if (extra) glds16(reinterpret_cast<const bf16_t*>(sptr[LPS_LO] + voff[LPS_LO]), base + dst[LPS_LO]);
-#pragma unroll
-    for (int i = 0; i < LPS_LO + 1; ++i) sptr[i] += more ? sadv[i] : 0u;
-  };
-  auto wait_stages_left = [&](auto n_c) {  // at most N later stages of this wave stay in flight
-    constexpr int N = decltype(n_c)::value;
-    if (extra) wait_vmcnt<N * (LPS_LO + 1)>();
-    else wait_vmcnt<N * LPS_LO>();
-  };
-
-#pragma unroll
-  for (int i = 0; i < MR; ++i)
-#pragma unroll
-    for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  unsigned a_nt[NST], b_nt[NST];                          // NT: per ring slot, + i * 1024 immediates
-  unsigned ta[MR][(NST + 1) / 2], tb[NR][(NST + 1) / 2];  // TN: per unit and slot pair {0,1} / {2,3}, + immediates
-  if constexpr (!TN) {
-    const int r = lane & 15, chunk = lane >> 4;
-    const unsigned lanepart = (unsigned)(r * 64 + ((chunk ^ ring_g(r)) << 4));
-#pragma unroll
-    for (int sl = 0; sl < NST; ++sl) {
-      a_nt[sl] = (unsigned)(sl * STAGE + wm * MR * 1024) + lanepart;
-      b_nt[sl] = (unsigned)(sl * STAGE + C::A_BYTES + wn * NR * 1024) + lanepart;
-    }
-  } else {
-    const unsigned l0 = lds_addr(smem);
-#pragma unroll
-    for (int i = 0; i < MR; ++i) {
-      unsigned off, dh;
-      TnImg<C::BM>::frag_off(TnImg<C::BM>::template unit_of<C::WGM, MR>(wm, i), lane, off, dh);
-      ta[i][0] = l0 + off;
-      ta[i][1] = l0 + off + 2 * STAGE;
-    }
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-      unsigned off, dh;
-      TnImg<C::BN>::frag_off(TnImg<C::BN>::template unit_of<C::WGN, NR>(wn, j), lane, off, dh);
-      tb[j][0] = l0 + C::A_BYTES + off;
-      tb[j][1] = l0 + C::A_BYTES + off + 2 * STAGE;
-    }
-  }
-
-  stage(SlotC<0>{}, 1 < nk);
-  stage(SlotC<1>{}, 2 < nk);
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();  // stages 0 and 1 landed
-
-  bf16x8 af[MR], bfr[NR];
-  auto body = [&](auto slot_c, int kt) {
-    constexpr int SLOT = decltype(slot_c)::value;
-    constexpr int NEXT = (SLOT + 2) % NST;
-    // A(kt)
-    stage(SlotC<NEXT>{}, kt + 3 < nk);
-    if (grp == 0) wait_stages_left(SlotC<2>{});
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // B(kt)
-    if constexpr (!TN) {
-#pragma unroll
-      for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + b_nt[SLOT] + j * 1024);
-#pragma unroll
-      for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_nt[SLOT] + i * 1024);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    } else {
-      constexpr int SO = (SLOT & 1) * STAGE, PAIR = SLOT / 2;
-      bf16x4 blo[NR], bhi[NR], alo[MR], ahi[MR];
-      tn_reads<C, SO, PAIR>(ta, tb, alo, ahi, blo, bhi);
-      // the asm reads are invisible to hipcc's counters: retire them by hand and pin the order
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < NR; ++j) bfr[j] = __builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7);
-#pragma unroll
-      for (int i = 0; i < MR; ++i) af[i] = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-    if (grp == 2) wait_stages_left(SlotC<1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    // C(kt)
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-      for (int j = 0; j < NR; ++j)
-        acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
-    if (grp == 1) wait_stages_left(SlotC<1>{});
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  // group g runs g slots behind group 0 (and leaves 2 - g slots early): everyone passes 3 * nk + 2 barriers
-  if (grp >= 1) __builtin_amdgcn_s_barrier();
-  if (grp == 2) __builtin_amdgcn_s_barrier();
-  for (int kt = 0; kt < nk; kt += NST) {
-    body(SlotC<0>{}, kt);
-    if (kt + 1 < nk) body(SlotC<1>{}, kt + 1);
-    if (kt + 2 < nk) body(SlotC<2>{}, kt + 2);
-    if (kt + 3 < nk) body(SlotC<3>{}, kt + 3);
-  }
-  if (grp <= 1) __builtin_amdgcn_s_barrier();
-  if (grp == 0) __builtin_amdgcn_s_barrier();
-  wait_vmcnt<0>();  // the run-ahead stages past the end of K: landed before the ring is reused for staging
-  __builtin_amdgcn_s_barrier();
-}
-
 // XCD-aware re-deal of the 1-D grid: block b runs on XCD b % 8 (observed); each XCD gets a contiguous
 // range of logical ids so neighbouring tiles (shared operand panels) hit one private L2.  Bijective.
 DEVINL int xcd_logical_id() {
@@ -698,7 +560,7 @@ template <int EPI>
 DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f32x4 v);
 
 template <class C, int EPI>
-__global__ __launch_bounds__(C::NW * 64, (C::NW / 4) * C::WGS_PER_CU) void big_nt_kernel(const GemmParams p) {
+__global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(const GemmParams p) {
   constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -745,8 +607,7 @@ __global__ __launch_bounds__(C::NW * 64, (C::NW / 4) * C::WGS_PER_CU) void big_n
     }
   }
   f32x4 acc[MR][NR];
-  if constexpr (C::NW == 12) big_mainloop3<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
-  else big_mainloop<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+  big_mainloop<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
 
   if (p.splitk > 1) {
     // In-launch split-K finish (cdna_hip_programming.md 5 "in-launch split-K reduction", write-through form):
@@ -1021,7 +882,7 @@ DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f
 // an XCD owns form a near-square patch (5 x 5 operand panels per K step instead of 24 + 24).
 // -------------------------------------------------------------------------------------------------
 template <class C, int PF>
-__global__ __launch_bounds__(C::NW * 64, C::NW == 12 ? 3 : 1) void big_tn_kernel(const TnGroup g) {
+__global__ __launch_bounds__(C::NW * 64, 1) void big_tn_kernel(const TnGroup g) {
   constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1072,51 +933,6 @@ __global__ __launch_bounds__(C::NW * 64, C::NW == 12 ? 3 : 1) void big_tn_kernel
   for (int i = 0; i < MR; ++i) mrow[i] = m0 + TnImg<BM>::template unit_of<C::WGM, MR>(wm, i) * 16;
 #pragma unroll
   for (int j = 0; j < NR; ++j) ncol[j] = n0 + TnImg<BN>::template unit_of<C::WGN, NR>(wn, j) * 16;
-  if constexpr (C::NW == 12) {
-    // experimental three-group loop: <= 168 VGPRs, so the read-modify-write of the gradient goes one tile row at a time
-    if (!pr.trans_out) {
-      big_mainloop3<C, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
-#pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        const int m = mrow[i] + (lane & 15);
-        float4 old[NR];
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          const int n = ncol[j] + (lane >> 4) * 4;
-          old[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (m < pr.M && n + 3 < pr.N) old[j] = *reinterpret_cast<const float4*>(pr.out + (size_t)m * pr.ldo + n);
-        }
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          const int n = ncol[j] + (lane >> 4) * 4;
-          if (m < pr.M && n + 3 < pr.N)
-            *reinterpret_cast<float4*>(pr.out + (size_t)m * pr.ldo + n) =
-                make_float4(old[j].x + acc[i][j][0], old[j].y + acc[i][j][1], old[j].z + acc[i][j][2], old[j].w + acc[i][j][3]);
-        }
-      }
-    } else {
-      big_mainloop3<C, true, false>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
-#pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        const int m = mrow[i] + (lane >> 4) * 4;
-        float4 old[NR];
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          const int n = ncol[j] + (lane & 15);
-          old[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (n < pr.N && m + 3 < pr.M) old[j] = *reinterpret_cast<const float4*>(pr.out + (size_t)n * pr.ldo + m);
-        }
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          const int n = ncol[j] + (lane & 15);
-          if (n < pr.N && m + 3 < pr.M)
-            *reinterpret_cast<float4*>(pr.out + (size_t)n * pr.ldo + m) =
-                make_float4(old[j].x + acc[i][j][0], old[j].y + acc[i][j][1], old[j].z + acc[i][j][2], old[j].w + acc[i][j][3]);
-        }
-      }
-    }
-    return;
-  }
   if (!pr.trans_out) {
     if constexpr (PF) tn_mainloop_pf<C, true, PF >= 2, (PF > 2 ? PF - 2 : 0)>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
     else big_mainloop<C, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
@@ -1222,9 +1038,6 @@ using Cfg160x256r6 = BigCfg<2, 5, 4, 4, 6>;  // 6-slot LDS-DMA ring (160 KiB) fo
 // 2 workgroups per CU (3-deep ring, 72 KiB; 64x64 wave tile -> <= 128 VGPRs): the epilogue of one workgroup (bias /
 // GELU math, staging, 35-70 MB of stores for the K = 800 GEMMs) runs under the main loop of the other
 using Cfg256x128 = BigCfg<4, 4, 2, 4, 3, 2>;
-using Cfg288x256w12 = BigCfg<3, 6, 4, 4>;  // experimental: 12 waves, three rotating groups (big_mainloop3)
-using Cfg288x160w12 = BigCfg<6, 3, 2, 5>;  // ... for the N = 800 outputs (48x80 wave tiles)
-using Cfg160x384w12 = BigCfg<2, 5, 6, 4>;  // ... grouped TN (weight gradients): 80x64 wave tiles, 130 tiles per cross layer
 
 template <int EPI>
 int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
@@ -1233,10 +1046,6 @@ int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
     case BIG_256x256: return launch_big_nt_cfg<Cfg256x256, EPI>(p, s);
     case BIG_256x160: return launch_big_nt_cfg<Cfg256x160, EPI>(p, s);
     case BIG_256x128: return launch_big_nt_cfg<Cfg256x128, EPI>(p, s);
-#ifdef FACT_EXPERIMENTAL_W12  // FACT_EXTRA_FLAGS=-DFACT_EXPERIMENTAL_W12 ./build.sh ; tools/bench_r2.py w12
-    case BIG_288x256_W12: return launch_big_nt_cfg<Cfg288x256w12, EPI>(p, s);
-    case BIG_288x160_W12: return launch_big_nt_cfg<Cfg288x160w12, EPI>(p, s);
-#endif
   }
   return -7;
 }
@@ -1252,8 +1061,6 @@ int big_tile_dims(int cfg, int* bm, int* bn) {
     case BIG_256x160: *bm = 256; *bn = 160; return 0;
     case BIG_160x256: *bm = 160; *bn = 256; return 0;
     case BIG_256x128: *bm = 256; *bn = 128; return 0;
-    case BIG_288x256_W12: *bm = 288; *bn = 256; return 0;
-    case BIG_288x160_W12: *bm = 288; *bn = 160; return 0;
   }
   return -1;
 }
@@ -1334,9 +1141,6 @@ int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
   if (g_tn_cfg == 1) return launch_big_tn_group_t<Cfg160x256, 1>(g, s, parts);
   if (g_tn_cfg == 2) return launch_big_tn_group_t<Cfg160x256, 2>(g, s, parts);
   if (g_tn_cfg == 6) return launch_big_tn_group_t<Cfg160x256r6, 2>(g, s, parts);  // interleaved loop, 6-slot ring
-#ifdef FACT_EXPERIMENTAL_W12
-  if (g_tn_cfg == 12) return launch_big_tn_group_t<Cfg160x384w12, 0>(g, s, parts);  // 12 waves, three rotating groups
-#endif
 #ifdef BIG_ABLATION
   if (g_tn_cfg == 3) return launch_big_tn_group_t<Cfg160x256, 3>(g, s, parts);  // interleaved loop without DMA
   if (g_tn_cfg == 4) return launch_big_tn_group_t<Cfg160x256, 4>(g, s, parts);  // ... without MFMAs

@@ -30,7 +30,7 @@ import struct
 
 import numpy as np
 
-from mint_amd.tfrecord import _enc_varint, _fields, _ld, _masked, _varint
+from mint_amd.tfrecord import _enc_varint, _fields, _ld, _masked, _varint, crc32c
 
 TABLE_MAGIC = 0xDB4775248B80FB57
 OBJECT_GRAPH_KEY = "_CHECKPOINTABLE_OBJECT_GRAPH"
@@ -192,30 +192,52 @@ class TensorBundleReader:
         if verify_crc and e["crc32c"] is not None and e["dtype"] != DT_STRING and _masked(raw) != e["crc32c"]:
             raise IOError("crc32c mismatch for %s" % key)
         if e["dtype"] == DT_STRING:
-            # string tensor: varint64 length per element, masked crc32c of the lengths (4 bytes), then the bytes
+            # scalar string tensor (tensor_bundle.cc WriteStringTensor): varint64 length, 4-byte masked crc32c of the
+            # length taken as a FIXED-WIDTH integer, then the bytes; the entry crc runs over fixed length | checksum | bytes
             n, p = _varint(raw, 0)
-            return bytes(raw[p + 4:p + 4 + n])
+            body = bytes(raw[p + 4:p + 4 + n])
+            if verify_crc:
+                len_ck, entry_ck = _string_checksums(body)
+                if struct.unpack("<I", raw[p:p + 4])[0] != len_ck:
+                    raise IOError("length checksum mismatch for %s" % key)
+                if e["crc32c"] is not None and e["crc32c"] != entry_ck:
+                    raise IOError("crc32c mismatch for %s" % key)
+            return body
         if e["dtype"] not in _NP_OF:
             raise ValueError("unsupported dtype %d for %s" % (e["dtype"], key))
         return np.frombuffer(raw, dtype=_NP_OF[e["dtype"]]).reshape(e["shape"]).copy()
+
+
+def _mask(c):
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _string_checksums(s):
+    """(length checksum, entry crc32c) of a scalar DT_STRING tensor the way TensorFlow's BundleWriter computes them:
+    element sizes are checksummed as fixed-width little-endian uint32 (uint64 above 4 GiB), NOT as the varints that are
+    stored; the running crc then extends over the 4 bytes of the masked length checksum and over the string bytes."""
+    fixed = struct.pack("<I", len(s)) if len(s) <= 0xFFFFFFFF else struct.pack("<Q", len(s))
+    len_ck = _mask(crc32c(fixed))
+    return len_ck, _mask(crc32c(fixed + struct.pack("<I", len_ck) + bytes(s)))
 
 
 def write_bundle(prefix, tensors, strings=None):
     """tensors: {key: ndarray}, strings: {key: bytes} (scalar DT_STRING) -> `<prefix>.index` / `.data-00000-of-00001`."""
     items, data = [(b"", _enc_varint(1 << 3) + _enc_varint(1) + _ld(3, _enc_varint(1 << 3) + _enc_varint(1)))], bytearray()
 
-    def entry(dtype, shape, payload):
+    def entry(dtype, shape, payload, crc=None):
         shp = b"".join(_ld(2, _enc_varint(1 << 3) + _enc_varint(int(s))) for s in shape)
         e = _enc_varint(1 << 3) + _enc_varint(dtype) + _ld(2, shp)
         e += _enc_varint(4 << 3) + _enc_varint(len(data)) + _enc_varint(5 << 3) + _enc_varint(len(payload))
-        e += _enc_varint((6 << 3) | 5) + struct.pack("<I", _masked(payload))
+        e += _enc_varint((6 << 3) | 5) + struct.pack("<I", _masked(payload) if crc is None else crc)
         data.extend(payload)
         return e
     for key in sorted(set(tensors) | set(strings or {})):
         if strings and key in strings:
             s = strings[key]
-            lens = _enc_varint(len(s))
-            items.append((key.encode("utf-8"), entry(DT_STRING, [], lens + struct.pack("<I", _masked(lens)) + s)))
+            len_ck, entry_ck = _string_checksums(s)
+            items.append((key.encode("utf-8"),
+                          entry(DT_STRING, [], _enc_varint(len(s)) + struct.pack("<I", len_ck) + s, crc=entry_ck)))
         else:
             a = np.asarray(tensors[key])
             if a.ndim:  # (ascontiguousarray would turn a scalar into shape (1,))
@@ -400,6 +422,8 @@ def read_fact_checkpoint(prefix, names, shapes=None, verify_crc=False):
         if len(slots["m"]) == len(names) and len(slots["v"]) == len(names):
             out["adam_m"], out["adam_v"] = slots["m"], slots["v"]
     gs = graph.walk(["global_step"])  # evaluator.py:64-67 Checkpoint(model=..., global_step=...)
+    if gs is None:
+        gs = graph.walk(["model", "global_step"])  # trainer.py:151 model_.global_step = optimizer.iterations
     if gs is not None and graph.variable_key(gs) in rd.entries:
         out["global_step"] = int(np.asarray(rd.get(graph.variable_key(gs))).reshape(-1)[0])
     return out
@@ -419,8 +443,12 @@ def write_fact_checkpoint(prefix, params, adam_m=None, adam_v=None, iterations=N
     if iterations is not None or adam_m is not None:
         opt = graph.add_path(["optimizer"])
         key = "optimizer/iter" + VAR_SUFFIX
-        graph.add_path(["optimizer", "iter"], key)
+        it_node = graph.add_path(["optimizer", "iter"], key)
         tensors[key] = np.asarray(int(iterations or 0), dtype=np.int64)
+        # the reference sets model_.global_step = optimizer.iterations (trainer.py:151) and the evaluator restores
+        # Checkpoint(model=, global_step=) (evaluator.py:64-67): both edges point at the same variable node
+        graph.nodes[graph.walk(["model"])]["children"]["global_step"] = it_node
+        graph.nodes[0]["children"]["global_step"] = it_node
         for sname, slot in (("m", adam_m), ("v", adam_v)):
             if slot is None:
                 continue

@@ -206,12 +206,9 @@ class SingleTaskTrainer:
                                       and dist.get_backend() == "nccl")
         # per-replica clipping needs the whole local gradient before anything is summed: no bucket overlap then
         self._overlap = bool(overlap_grad_allreduce) and not (grad_clip_norm > 0.)  # reducer is created lazily
-        # Optimizer step inside backward (engine API, no global-norm clipping), single replica only: the
-        # engine holds the head + cross-modal buckets back until the cross-modal backward is done and
-        # updates them beside the two small encoder stacks' backward (10.27 vs 10.35 ms/step at B = 16).
-        # Updating every bucket as soon as it is final - which is what the data-parallel reducer would
-        # have to do behind each all-reduce - slows the dense backward by more than it hides
-        # (11.51 vs 11.22 ms), so with more than one replica Adam is one pass after the all-reduce.
+        # Optimizer step inside backward (engine API, no global-norm clipping).  Single replica: the engine holds the
+        # head + cross-modal buckets back until the cross-modal backward is done and updates them beside the two small
+        # encoder stacks' backward.  Data parallel: see `dp_fused_adam` below.
         self._fuse = bool(fuse_optimizer) and hasattr(model, "begin_fused_adam") and not (grad_clip_norm > 0.)
         # Data parallel: Adam of a bucket runs behind that bucket's all-reduce (communication stream) instead of as
         # one pass after the last all-reduce - that pass is 0.8-0.9 ms of an 8.2 ms step that nothing overlaps.
@@ -246,6 +243,12 @@ class SingleTaskTrainer:
         fused = (self._fuse and R == 1 and self._reducer is None) or dp_fused
         step = self.optimizer.iterations  # summaries are written at the PRE-update step (:172-173)
         lr_used = None
+        output = None
+        if self.metrics:
+            # user metrics see (target, output) of the PRE-update weights, like the reference's `output` of the taped
+            # forward (:151,194-196): run that forward before anything can update the parameters (one extra pass;
+            # FACT's get_metrics() is empty, so the hot path never pays it)
+            output = self.model(inputs, training=True)
         if self._reducer is not None:
             self._reducer.fused_adam = dp_fused
         if fused:
@@ -281,8 +284,7 @@ class SingleTaskTrainer:
         self.regularization_loss.update_state(regularization_loss)
         # the reference reports the schedule at the POST-increment iteration count (:192-193)
         self.learning_rate.update_state(self.optimizer.learning_rate(self.optimizer.iterations))
-        if self.metrics:  # user metrics see (target, output): costs one extra forward pass
-            output = self.model(inputs, training=True)
+        if self.metrics:
             for metric in self.metrics:
                 metric.update_state(target, output)
         return total_loss

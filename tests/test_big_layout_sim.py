@@ -40,7 +40,7 @@ class TnImg:
         return self.N128 * 8192 + (g * 8 + (s >> 2)) * 64 + ((u ^ (g & 1)) << 5) + (s & 3) * 8, 4 * 64
 
 
-@pytest.mark.parametrize("W", [160, 256, 128, 32, 384])   # 384: the experimental 160x384 grouped-TN tile
+@pytest.mark.parametrize("W", [160, 256, 128, 32])
 def test_tn_image_fragments_and_banks(W):
     img = TnImg(W)
     # operand tile A[k][m] = k * 1000 + m (exact in int32); LDS image as 2-byte elements
@@ -107,9 +107,7 @@ def test_nt_ring_image(rows):
             assert len({(addrs[l] // 16) % 16 for l in g}) == 16
 
 
-CFGS = {"288x256": (2, 9, 4, 4), "256x256": (2, 8, 4, 4), "256x160": (4, 4, 2, 5), "160x256": (2, 5, 4, 4),
-        # experimental 12-wave configs (big_mainloop3, -DFACT_EXPERIMENTAL_W12)
-        "w12-288x256": (3, 6, 4, 4), "w12-288x160": (6, 3, 2, 5), "w12-160x384": (2, 5, 6, 4)}
+CFGS = {"288x256": (2, 9, 4, 4), "256x256": (2, 8, 4, 4), "256x160": (4, 4, 2, 5), "160x256": (2, 5, 4, 4)}
 
 
 def pick_ch(MR, regions_bytes_per_rowtile, lds_bytes, nout=1, nw=8):
@@ -119,7 +117,7 @@ def pick_ch(MR, regions_bytes_per_rowtile, lds_bytes, nout=1, nw=8):
     return 1
 
 
-@pytest.mark.parametrize("name", ["w12-288x256", "w12-288x160", "w12-160x384", "288x256", "160x256"])
+@pytest.mark.parametrize("name", ["288x256", "256x256", "256x160", "160x256"])
 def test_dma_pieces_cover_a_stage_once(name):
     """wave w issues pieces w*LPS .. and, for w < EXTRA, piece NW*LPS + w (BigCfg): every 1 KiB piece of a stage exactly once"""
     WGM, MR, WGN, NR = CFGS[name]
@@ -132,11 +130,9 @@ def test_dma_pieces_cover_a_stage_once(name):
             issued.append(nw * lps + w)
     assert sorted(issued) == list(range(npiece))
     assert 4 * npiece * 1024 <= 160 * 1024            # 4-slot ring fits the LDS
-    if nw == 12:                                      # three groups of four consecutive waves; <= 170 VGPRs per wave
-        assert 4 * MR * NR + 4 * (MR + NR) <= 150
 
 
-@pytest.mark.parametrize("name,side", [("w12-160x384", "A"), ("w12-160x384", "B"), ("160x256", "A"), ("160x256", "B")])
+@pytest.mark.parametrize("name,side", [("160x256", "A"), ("160x256", "B")])
 def test_tn_unit_split_covers_the_operand(name, side):
     """TnImg::unit_of: the 16-column units of an operand are dealt to the waves along it so that every unit is owned by
     exactly one wave index and the main / tail split is the same for every wave (compile-time hh increments)."""
@@ -152,7 +148,7 @@ def test_tn_unit_split_covers_the_operand(name, side):
     assert sorted(units) == list(range(W // 16))
 
 
-@pytest.mark.parametrize("name", ["288x256", "256x256", "256x160", "w12-288x256", "w12-288x160"])
+@pytest.mark.parametrize("name", ["288x256", "256x256", "256x160"])
 @pytest.mark.parametrize("esize,nout", [(2, 1), (2, 2), (4, 1)])
 def test_staged_epilogue_maps(name, esize, nout):
     WGM, MR, WGN, NR = CFGS[name]

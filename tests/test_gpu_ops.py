@@ -104,16 +104,8 @@ def gemm_path(request):
     L.lib().fact_debug_force_generic_gemm(0)
 
 
-# FACT_EXPERIMENTAL_W12=1 (with FACT_LIB pointing at a library built with -DFACT_EXPERIMENTAL_W12, tools/build_variant.sh)
-# adds the not-yet-shipped 12-wave three-group kernels to the kernel-choice fixtures below; the default suite does not
-# contain them.
-import os  # noqa: E402
-_EXP_W12 = os.environ.get("FACT_EXPERIMENTAL_W12") == "1"
-
-
-@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14] + ([15, 16] if _EXP_W12 else []),
-                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160", "big256x128x2"]
-                + (["w12-288x256", "w12-288x160"] if _EXP_W12 else []))
+@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14],
+                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160", "big256x128x2"])
 def nt_variant(request):
     """NT kernel choice: the engine's automatic pick, the 128x128 kernel, the round-1 big-tile kernels and
     every tile config of the big-tile family (gemm_big.hip), forced regardless of the tile-count heuristic."""
@@ -266,7 +258,7 @@ def _tn_group(probs, K):
     _sync()
 
 
-@pytest.fixture(params=[0] + ([12] if _EXP_W12 else []), ids=["staggered"] + (["w12-160x384"] if _EXP_W12 else []))
+@pytest.fixture(params=[0, 2], ids=["staggered", "interleaved"])
 def tn_group_loop(request):
     """main loop / tile config of the grouped wgrad kernel (engine option tn_loop)"""
     L.lib().fact_debug_gemm_tn_cfg(request.param)

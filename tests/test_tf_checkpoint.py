@@ -278,3 +278,56 @@ def test_written_bundle_parses_with_the_official_protobuf_runtime(tmp_path):
         np.testing.assert_array_equal(rd.get(key), ref[name])
     it = [a.checkpoint_key for a in g.nodes[walk(["optimizer", "iter"])].attributes][0]
     assert int(rd.get(it).reshape(-1)[0]) == 7
+
+
+def test_string_tensor_checksums_follow_bundle_writer_rule(tmp_path):
+    """TensorFlow's BundleWriter (tensor_bundle.cc WriteStringTensor) checksums the element sizes of a DT_STRING tensor
+    as FIXED-WIDTH uint32, not as the varints it stores, then extends the entry crc over the 4 bytes of the masked length
+    checksum and over the string bytes; BundleReader rejects anything else ("length checksum does not match").  The
+    expectation below is a bit-by-bit CRC-32C written out independently of mint_amd's table-driven routine."""
+    def crc_bitwise(data, crc=0):
+        crc ^= 0xFFFFFFFF
+        for b in data:
+            crc ^= b
+            for _ in range(8):
+                crc = (crc >> 1) ^ 0x82F63B78 if crc & 1 else crc >> 1
+        return crc ^ 0xFFFFFFFF
+
+    def mask(c):
+        return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+    payload = bytes(range(256)) * 3 + b"object graph"   # 780 bytes: the varint length is 2 bytes (0x8c 0x06)
+    prefix = str(tmp_path / "ckpt-1")
+    T.write_bundle(prefix, {"x": np.arange(4, dtype=np.float32)}, {"_CHECKPOINTABLE_OBJECT_GRAPH": payload})
+    rd = T.TensorBundleReader(prefix)
+    e = rd.entries["_CHECKPOINTABLE_OBJECT_GRAPH"]
+    raw = rd._raw(e)
+    assert raw[:2] == b"\x8c\x06"
+    c = crc_bitwise(struct.pack("<I", len(payload)))
+    assert struct.unpack("<I", raw[2:6])[0] == mask(c)
+    c = crc_bitwise(struct.pack("<I", mask(c)), c)   # Extend(crc, &length_checksum, 4)
+    c = crc_bitwise(payload, c)                     # Extend(crc, string bytes)
+    assert e["crc32c"] == mask(c)
+    assert rd.get("_CHECKPOINTABLE_OBJECT_GRAPH", verify_crc=True) == payload
+    # a corrupted length checksum / payload byte is detected on read
+    data_path = prefix + ".data-00000-of-00001"
+    blob = bytearray(open(data_path, "rb").read())
+    blob[e["offset"] + 10] ^= 1
+    open(data_path, "wb").write(bytes(blob))
+    with pytest.raises(IOError):
+        T.TensorBundleReader(prefix).get("_CHECKPOINTABLE_OBJECT_GRAPH", verify_crc=True)
+
+
+def test_exported_graph_carries_the_step_counter_edges(tmp_path):
+    """trainer.py:151 `model_.global_step = optimizer.iterations` and evaluator.py:64-67 Checkpoint(model=, global_step=):
+    the exported graph has `model/global_step` and a root `global_step` edge onto the optimizer/iter variable."""
+    shapes, params, _, _ = _tiny_state()
+    names = list(shapes)
+    prefix = str(tmp_path / "ckpt-7")
+    T.write_fact_checkpoint(prefix, params, iterations=7)
+    rd = T.TensorBundleReader(prefix)
+    graph = T.ObjectGraph(rd.get(T.OBJECT_GRAPH_KEY, verify_crc=True))
+    it = graph.walk(["optimizer", "iter"])
+    assert it is not None and graph.walk(["global_step"]) == it and graph.walk(["model", "global_step"]) == it
+    got = T.read_fact_checkpoint(prefix, names)
+    assert got["iterations"] == 7 and got["global_step"] == 7

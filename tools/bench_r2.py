@@ -147,19 +147,6 @@ if __name__ == "__main__":
             nt_case(Me, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 12], "enc out-proj")
             nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [1, 10, 11, 14], "enc FFN1")
         nt_case(8192, 8192, 8192, L.EPI_BF16, [1, 7, 11], "8192^3")
-    if what == "w12":  # experimental 12-wave three-group loop (nt_variant 15) against the shipped 8-wave 288x256 (10)
-        for (M, N, K) in ((300, 500, 96), (288, 256, 32), (577, 260, 160), (64, 72, 64), (5760, 3072, 64)):
-            nt_case(M, N, K, L.EPI_BF16, [10, 15], "parity")
-        nt_case(5760, 3072, 800, L.EPI_BF16, [10, 15], "plain")
-        nt_case(5760, 3072, 800, L.EPI_BIAS_GELU, [10, 15], "FFN1+gelu")
-        nt_case(5760, 3072, 800, L.EPI_GELU_BWD, [10, 15], "dgrad gelu'")
-        nt_case(5760, 2400, 800, L.EPI_BF16, [11, 10, 15], "QKV (plain)")
-        nt_case(5760, 3072, 3072, L.EPI_BF16, [10, 15], "long K")
-        nt_case(5760, 800, 3072, L.EPI_F32_BIAS_RESID, [12, 16], "FFN2+resid")   # 16 = 288x160 on 12 waves
-        nt_case(5760, 800, 3072, L.EPI_BF16, [12, 16], "dgrad FFN1")
-        nt_case(5760, 800, 800, L.EPI_F32_BIAS_RESID, [14, 12, 16], "out-proj+resid")
-        nt_case(300, 800, 96, L.EPI_BF16, [12, 16], "parity N800")
-        nt_case(8192, 8192, 8192, L.EPI_BF16, [11, 10, 15], "8192^3")
     if what == "small":
         for Me in (5760, 3840, 1920):
             nt_case(Me, 800, 800, L.EPI_BF16, [1, 112, 14], "N800 K800 bf16")
