@@ -237,7 +237,7 @@ struct FactHandle {
   int ln_split = 1;   // LayerNorm backward: row-wise dx kernel on the chain, parameter gradients on the wgrad stream
   int wgrad_parts = 2;   // launches per layer of the grouped wgrad kernel (each ~190/parts workgroups wide)
   int wgrad_defer = 1;   // release a layer's wgrad batch behind the NEXT layer's GELU' dgrad (240 workgroups)
-  int bwd_splitk = 0;    // in-kernel split-K for the N = 800 dgrad GEMMs (they share the chip with the wgrad launches)
+  int bwd_splitk = 0;    // in-kernel split-K for the N = 800 dgrad GEMMs: 1 = always, 2 = stacks of <= 4096 rows (encoders)
   int sr_rows = 1;       // supervised-rows shortcut of the last cross-modal layer in fact_forward_backward (SrBuf)
   SrBuf sr;
   float* skinny_acc = nullptr;  // zero-filled fp32 accumulator of the skinny-M GEMMs of that layer (caller's stream)
@@ -262,6 +262,8 @@ struct FactHandle {
   int use_aux = 1;   // third stream for the motion stack's backward chain (0: on the caller's stream - the data-parallel
                      // trainer sets it: with its communication stream and RCCL's own the process would have more
                      // streams than the 4 hardware queues HIP gives it, and streams that share a queue serialise)
+  int skip = 0;               // TIMING-ONLY ablation mask (results are wrong): 1 wgrad 2 col sums 4 attn bwd 8 ln bwd 16 gelu' dgrad
+                              // 32 ffn1 dgrad 64 qkv dgrad 128 out-proj dgrad 256 attn fwd 512 ln fwd
   int adam_hold = 1;          // in-backward optimizer: hold the head + cross buckets until the last is final
   // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
   fact_grad_cb cb = nullptr;
@@ -978,7 +980,7 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
   {
     KScope k(h, KP_WGRAD, w, 2.0 * (double)M * ((double)d * ff * 2 + (double)d * d * 4), 0,
              h->wgrad_big ? h->wgrad_parts : 8);
-    const int rc = wgrad_layer_group(h, st, p, a, b.xin16, b.dpre, b.xmid16, b.dqkv, M, w);
+    const int rc = (h->skip & 1) ? 0 : wgrad_layer_group(h, st, p, a, b.xin16, b.dpre, b.xmid16, b.dqkv, M, w);
     if (rc < 0) return rc;
     if (rc > 0) {
       CHK(wgrad(h, a.g, fp, ff, b.xin16, dp, d, M, G(h, p.w2.w), d, w, b.slab));
@@ -1007,7 +1009,7 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
     ts.t[2].dh = b.dh1; ts.t[2].ld16 = dp; ts.t[2].x = a.x_in; ts.t[2].mean = a.mean1; ts.t[2].rstd = a.rstd1;
     ts.t[2].dy = b.xmid16; ts.t[2].ldy = dp; ts.t[2].dgamma = G(h, p.ln1_g); ts.t[2].dbeta = G(h, p.ln1_b);
     ts.t[2].dbias = G(h, p.bo); ts.t[2].C = d;
-    CHK(launch_col_tasks(ts, c));
+    if (!(h->skip & 2)) CHK(launch_col_tasks(ts, c));
   } else {
     KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * ff * 2.0, 1);
     CHK(launch_colsum_bf16(b.dpre, fp, G(h, p.b1), M, ff, ff, c));
@@ -1061,18 +1063,19 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
     KScope k(h, KP_GELU_DGRAD, s, 2.0 * Md * ff * d);
     GemmParams g = gp(xin16, dp, p.w2.s, p.w2.lds, M, ff, d);
     g.ep.out0 = dpre; g.ep.ldo0 = fp; g.ep.pre = a.pre; g.ep.ldp = fp;
-    CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
+    if (!(h->skip & 16)) CHK(launch_gemm_nt(EPI_GELU_BWD, g, s));
   }
   CHK(flush_batch(h, sc));  // the previous layer's batch: released behind the kernel just enqueued
   {
     KScope k(h, KP_DFFN1, s, 2.0 * Md * ff * d);
     GemmParams g = gp(dpre, fp, p.w1.s, p.w1.lds, M, d, ff);
     g.ep.out0 = dh2; g.ep.ldo0 = dp;
-    if (h->bwd_splitk) with_ws(h, g, s);
-    CHK(launch_gemm_nt(EPI_BF16, g, s));
+    if (h->bwd_splitk == 1 || (h->bwd_splitk == 2 && M <= 4096)) with_ws(h, g, s);
+    if (!(h->skip & 32)) CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
   KScope* kln = new KScope(h, KP_LN_BWD, s, 0, Md * d * 16.0);
-  if (split)
+  if (h->skip & 8) {
+  } else if (split)
     CHK(launch_ln_bwd_dx(dh2, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, M, d, dp, s));
   else
     CHK(launch_ln_bwd(dh2, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, G(h, p.ln2_g),
@@ -1084,20 +1087,20 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
     GemmParams g = gp(xmid16, dp, p.wo.s, p.wo.lds, M, d, d);
     bf16_t* row[1] = {sc.dorow};
     heads_ep(g.ep, st, row, 1);
-    CHK(launch_gemm_nt(EPI_HEADS, g, s));
+    if (!(h->skip & 128)) CHK(launch_gemm_nt(EPI_HEADS, g, s));
   }
   {
     KScope k(h, KP_ATTN_BWD, s, 2.5 * fl_attn, 0, 2);
     AttnParams ap = attn_params(st, a, B);
     ap.dorow = sc.dorow; ap.dsum = sc.dsum; ap.dqkv = dqkv;
-    CHK(launch_attn_bwd(ap, s));
+    if (!(h->skip & 4)) CHK(launch_attn_bwd(ap, s));
   }
   {
     KScope k(h, KP_DQKV, s, 2.0 * Md * 3 * d * d);
     GemmParams g = gp(dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
     g.ep.out0 = dh1; g.ep.ldo0 = dp;
-    if (h->bwd_splitk) with_ws(h, g, s);
-    CHK(launch_gemm_nt(EPI_BF16, g, s));
+    if (h->bwd_splitk == 1 || (h->bwd_splitk == 2 && M <= 4096)) with_ws(h, g, s);
+    if (!(h->skip & 64)) CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
   // ---- everything only the optimizer reads: recorded now, released by the next layer (or the caller)
   {
@@ -1115,7 +1118,8 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
     sc.ev_waited = sc.ev_batch[qr];  // the next layer's entry wait is for this same event
   }
   KScope kln1(h, KP_LN_BWD, s, 0, Md * d * 16.0);
-  if (split)
+  if (h->skip & 8) {
+  } else if (split)
     CHK(launch_ln_bwd_dx(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, M, d, dp, s));
   else
     CHK(launch_ln_bwd(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, G(h, p.ln1_g),
@@ -1195,7 +1199,7 @@ int layer_backward_sr(FactHandle* h, Stack& st, int l, int B, int T, float* dx, 
     KScope k(h, KP_DQKV, s, 2.0 * Md * 3 * d * d);
     GemmParams g = gp(dqkv, qp, p.wqkv.s, p.wqkv.lds, M, d, 3 * d);
     g.ep.out0 = dh1; g.ep.ldo0 = dp;
-    if (h->bwd_splitk) with_ws(h, g, s);
+    if (h->bwd_splitk == 1 || (h->bwd_splitk == 2 && M <= 4096)) with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
   // residual gradient of all rows: the compact rows scattered, zero elsewhere
@@ -1344,6 +1348,17 @@ unsigned int fact_crc32c(const void* data, size_t n, unsigned int crc) {
 }
 const char* fact_last_error(void) { return g_err.c_str(); }
 
+// Engine streams; an environment variable (A/B knob) may ask for a dispatch priority: -1 = highest, 1 = lowest the
+// device offers, unset / 0 = default.
+static hipError_t make_stream(hipStream_t* s, const char* env) {
+  const char* v = getenv(env);
+  const int want = v ? atoi(v) : 0;
+  if (!want) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  return hipStreamCreateWithPriority(s, hipStreamNonBlocking, want > 0 ? least : greatest);
+}
+
 static void init_geo(FactHandle* h, const FactConfig* cfg) {
   h->cfg = *cfg;
   if (h->cfg.ln_eps <= 0.f) h->cfg.ln_eps = 1e-5f;
@@ -1427,8 +1442,8 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
   }
   // (Stream priorities were tried for the wgrad / column-sum streams in round 2: no gain for the dgrad chain,
   //  and with a second low-priority stream the step time doubled on this runtime - all streams stay default.)
-  HIPCHK(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+  HIPCHK(make_stream(&h->side, "FACT_PRIO_SIDE"));
+  HIPCHK(make_stream(&h->aux, "FACT_PRIO_AUX"));
   for (int i = 0; i < 3; ++i) {
     HIPCHK(hipMalloc((void**)&h->sk_slab[i], kSplitKSlabBytes));
     HIPCHK(hipMalloc((void**)&h->sk_cnt[i], kSplitKCounters * sizeof(unsigned)));
@@ -1526,6 +1541,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
   if (!strcmp(key, "lite_stream")) {
     if (value && !h->lite) HIPCHK(hipStreamCreateWithFlags(&h->lite, hipStreamNonBlocking));
     h->use_lite = value;
+    return 0;
+  }
+  if (!strcmp(key, "skip")) {
+    h->skip = value;
     return 0;
   }
   if (!strcmp(key, "adam_hold")) {
@@ -1747,7 +1766,7 @@ int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps
   h->adam.gscale = 1.0f;
   // created on first use, and only when the engine itself will enqueue the updates (with a gradient callback the
   // host calls fact_adam_bucket on its communication stream: one stream less competing for the hardware queues)
-  if (!h->opt && !h->cb) HIPCHK(hipStreamCreateWithFlags(&h->opt, hipStreamNonBlocking));
+  if (!h->opt && !h->cb) HIPCHK(make_stream(&h->opt, "FACT_PRIO_OPT"));
   h->adam_pending = true;
   return 0;
 }

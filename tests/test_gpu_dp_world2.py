@@ -27,7 +27,7 @@ def _rdzv():
     return path
 
 
-def _worker(rank, world, path, q, bf16, fused):
+def _worker(rank, world, path, q, bf16, fused, clip=0.0, steps=STEPS):
     try:
         import torch.distributed as dist
         from mint_amd import model_builder
@@ -40,13 +40,25 @@ def _worker(rank, world, path, q, bf16, fused):
         full = O.synthetic_batch(cfg, PER_RANK * world, T, seed=5)
         mine = {k: v[PER_RANK * rank:PER_RANK * (rank + 1)].float().cuda() for k, v in full.items()}
         model = model_builder.build(make_config(cfg), True)
-        tr = SingleTaskTrainer([mine] * STEPS, "target", model, optimizer=Adam(1e-3), overlap_grad_allreduce=True,
-                               bf16_grad_buckets=bf16, dp_fused_adam=fused)
+        STEPS_ = steps
+        tr = SingleTaskTrainer([mine] * STEPS_, "target", model, optimizer=Adam(1e-3), overlap_grad_allreduce=True,
+                               bf16_grad_buckets=bf16, dp_fused_adam=fused, grad_clip_norm=clip)
         assert tr.num_replicas_in_sync == world
+        if clip > 0:  # the oracle needs the initial weights: identical on every rank (seeded initialisers)
+            model.build(PER_RANK, 225, 35)
+            init = {n: v.detach().cpu().double().numpy().copy() for n, v in zip(model.variable_names, model.trainable_variables)}
         tr.train_loop_begin()
-        it = iter([mine] * STEPS)
-        losses = [float(tr.train_step(it)) for _ in range(STEPS)]
+        it = iter([mine] * STEPS_)
+        losses = [float(tr.train_step(it)) for _ in range(STEPS_)]
         torch.cuda.synchronize()
+        if clip > 0:  # per-replica clipping needs the whole local gradient: no bucket overlap, one Adam pass after the sum
+            assert tr._reducer is None
+            metrics = tr.train_loop_end()
+            views = {n: model._arena["adam_m"][off:off + r * c].cpu().double().numpy().copy() for (n, off, r, c, _k) in model._table}
+            q.put((rank, "ok", init, losses, views, None))
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         assert tr._reducer is not None and tr._reducer.fused_adam == bool(fused) and tr._reducer.bf16 == bf16
         metrics = tr.train_loop_end()
         flat = torch.cat([v.flatten() for v in model.trainable_variables]).cpu().numpy().copy()
@@ -59,11 +71,11 @@ def _worker(rank, world, path, q, bf16, fused):
         raise
 
 
-def _run_world2(bf16, fused):
+def _run_world2(bf16, fused, clip=0.0, steps=STEPS):
     path = _rdzv()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, path, q, bf16, fused)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, path, q, bf16, fused, clip, steps)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -128,3 +140,32 @@ def test_engine_two_replicas_one_gpu(bf16, fused):
     assert c > 0.998, c
     # second moments (no sign sensitivity): per-element squares of the summed gradient
     assert dv < (2e-2 if bf16 else 5e-3), dv   # measured 3.5e-3 / 0.9e-3
+
+
+def test_two_replicas_clip_their_own_gradient_before_the_sum():
+    """single_task_trainer.py:180-187 under MirroredStrategy: tf.clip_by_global_norm runs inside the per-replica train_fn,
+    i.e. on each replica's OWN gradient of loss / R, and apply_gradients then SUMS the clipped gradients.  One step at
+    world 2 (two processes on cuda:0, gloo); expectation from the oracle: m1 = (1 - b1) * sum_r clip(g_r)."""
+    clip = 0.02   # well below either replica's gradient norm (checked below): both replicas clip, by different factors
+    res = _run_world2(False, False, clip=clip, steps=1)
+    cfg = O.TINY_CFG
+    full = O.synthetic_batch(cfg, PER_RANK * 2, T, seed=5)
+    params = {n: torch.from_numpy(a) for n, a in res[0][0].items()}
+    for n in params:
+        assert np.array_equal(res[0][0][n], res[1][0][n])
+    summed, scales = None, []
+    for r in range(2):
+        sl = {k: v[PER_RANK * r:PER_RANK * (r + 1)] for k, v in full.items()}
+        _, g, _ = O.loss_and_grads(params, cfg, sl["motion_input"], sl["audio_input"], sl["target"], 2)
+        gn = float(sum(float((t.double() ** 2).sum()) for t in g.values()) ** 0.5)
+        assert gn > 2 * clip
+        scales.append(clip / gn)
+        g = {k: t * (clip / gn) for k, t in g.items()}
+        summed = g if summed is None else {k: summed[k] + g[k] for k in g}
+    assert abs(scales[0] - scales[1]) / scales[0] > 1e-3   # per-replica factors differ: clip-after-sum would not match
+    worst = 0.0
+    for n, m_np in res[0][2].items():
+        m_dev, ref = torch.from_numpy(m_np), (0.1 * summed[n]).flatten()
+        worst = max(worst, float((m_dev - ref).norm() / (ref.norm() + 1e-30)))
+        assert np.array_equal(m_np, res[1][2][n]), "replicas diverged: %s" % n
+    assert worst < 5e-2, worst

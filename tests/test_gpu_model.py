@@ -673,3 +673,42 @@ def test_scaled_config_full_depth_step_vs_oracle():
         worst = min(worst, (cos(g, ref_grads[name]), name))
     assert worst[0] > 0.999, worst
     print("scaled FACT full depth: worst gradient cosine %.5f (%s)" % worst)
+
+
+def test_clip_by_global_norm_in_adam_step_vs_oracle():
+    """tf.clip_by_global_norm before apply_gradients (single_task_trainer.py:180-183; engine: fact_adam_step with
+    clip_norm > 0): two optimizer steps with a clip norm well below the gradient norm, against the oracle's
+    adam_update(clip_norm=...).  Adam's update direction is almost scale-invariant, the MOMENTS are not: a clip that
+    is skipped (or applied per tensor instead of globally) leaves m off by 1/scale and v by 1/scale^2."""
+    cfg = O.TINY_CFG
+    model = model_builder.build(make_config(cfg), True)
+    batch = O.synthetic_batch(cfg, 4, 8, seed=11)
+    gb = gpu_batch(batch)
+    model.build(4, 225, 35)
+    _randomize(model, seed=7)
+    params = oracle_params(model)
+    _, g0, _ = O.loss_and_grads(params, cfg, batch["motion_input"], batch["audio_input"], batch["target"])
+    gnorm = float(sum(float((g.double() ** 2).sum()) for g in g0.values()) ** 0.5)
+    clip = 0.25 * gnorm                                   # active clip: scale 0.25 at step 0
+    m = {k: torch.zeros_like(v) for k, v in params.items()}
+    v = {k: torch.zeros_like(vv) for k, vv in params.items()}
+    m_noclip = None
+    trainer = SingleTaskTrainer([gb] * 2, "target", model, optimizer=Adam(1e-3), grad_clip_norm=clip)
+    it = iter([gb] * 2)
+    for step in range(2):
+        trainer.train_step(it)
+        if step == 0:
+            _, _, _, m_noclip, _ = O.train_step(params, m, v, 0, cfg, batch, 1e-3)       # what a skipped clip would give
+        _, _, params, m, v = O.train_step(params, m, v, step, cfg, batch, 1e-3, clip_norm=clip)
+    torch.cuda.synchronize()
+    st = model.state_dict()
+    views = lambda arena: {n: arena[off:off + r * c].double() for (n, off, r, c, _k) in model._table}
+    pm, pv, pp = views(st["adam_m"]), views(st["adam_v"]), views(st["params"])
+    worst_m = max(rel(pm[n], m[n].flatten()) for n in model.variable_names)
+    worst_v = max(rel(pv[n], v[n].flatten()) for n in model.variable_names)
+    assert worst_m < 5e-2 and worst_v < 1e-1, (worst_m, worst_v)
+    for n in model.variable_names:
+        assert rel(pp[n], params[n].flatten()) < 1e-2, n
+    # the test has teeth: the un-clipped first moment is ~4x the clipped one
+    some = "cross_modal_layer/output/kernel"
+    assert float(m_noclip[some].norm()) > 2.0 * float(pm[some].norm())
