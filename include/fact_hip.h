@@ -161,7 +161,7 @@ int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, i
 typedef void (*fact_grad_cb)(void* user, int bucket, size_t offset_floats, size_t count_floats);
 int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* comm_stream);
 
-/* Engine knobs (all default to 1; the 0 settings are the reference paths the tests compare against):
+/* Engine knobs (default 1 unless stated; the 0 settings are the reference paths the tests compare against):
  *   "wgrad_tr"       1 = wgrad GEMM builds its fragments with the LDS transpose read, 0 = explicit transposes
  *   "wgrad_slab"     1 = split-K partials as plain stores + a streaming reduce, 0 = fp32 atomics
  *   "side_stream"    1 = wgrad batches / the audio encoder run on the handle's second stream, 0 = one stream
@@ -171,9 +171,17 @@ int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* com
  *                        (fact_model.py:128), whose GEMMs of <= 512 rows are then cut along K (fp32 atomics: equal up to
  *                        summation order, not bit for bit from run to run); 0 = every layer on all rows.  fact_forward is
  *                        never affected.
+ *   "grad_overwrite" (default 0) 1 = fact_forward_backward WRITES the gradient of every transformer-layer Dense kernel
+ *                        (plain stores of the whole-K grouped wgrad launch) instead of adding to it, and the optimizer
+ *                        pass leaves those ranges as they are instead of zeroing them: 32 instead of 36 bytes per
+ *                        parameter in the optimizer pass and no read-modify-write in the wgrad epilogue.  For hosts that
+ *                        call fact_forward_backward exactly once per optimizer step (mint_amd/trainer.py sets it; the
+ *                        reference's train_fn has no gradient accumulation either, single_task_trainer.py:141-196);
+ *                        with 0 gradients accumulate across calls until fact_adam_step zeroes them.
  *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "bwd_splitk", "aux_stream", "adam_hold", "tn_loop",
- *   "attn_variant", "big_impl", "lite_stream": scheduling / kernel-selection knobs of the A/B runs documented in DESIGN.md
- *   sections 3 and 6; results are unchanged by them.
+ *   "attn_variant", "adam_variant", "big_impl", "lite_stream": scheduling / kernel-selection knobs of the A/B runs
+ *   documented in DESIGN.md sections 3 and 6; results are unchanged by them.  "skip": timing-only ablation mask
+ *   (DESIGN 6), results are WRONG while it is set.
  * Unknown keys return an error. */
 int fact_set_option(FactHandle* h, const char* key, int value);
 

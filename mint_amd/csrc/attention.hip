@@ -1445,7 +1445,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_st_kernel(const AttnPara
   }
 }
 
-int g_attn_variant = 1;  // 1 = LDS-resident kernels when the head fits, tiled otherwise (default: measured equal or better in the train step); 2 = streaming family
+// 1 = LDS-resident kernels when the head fits (tiled otherwise), 2 = streaming family, 3 = streaming forward + resident
+// backward (default, round 3: the forward runs alone on the chip, where the 480-workgroup streaming kernel is 4 us
+// shorter; the backward kernels run beside the 95-workgroup wgrad launches, where the 160-workgroup resident ones leave
+// it the CUs - same-box A/B of the step: 7.97-7.99 / 7.94-7.95 / 7.87-7.90 / 8.00-8.01 ms for 1 / 2 / 3 / 4), 4 = the reverse
+int g_attn_variant = 3;
 int g_attn_force_tiled = 0;  // test knob: 1 = always use the tiled (streaming) kernels
 
 // LDS bytes of the resident kernels for n tokens; 0 = does not fit -> tiled kernels
@@ -1497,7 +1501,7 @@ int allow_lds_bytes(K kernel, bool* done, size_t bytes) {
 
 template <int DH>
 int fwd_t(const AttnParams& p, hipStream_t s) {
-  if constexpr (DH <= 96) if (g_attn_variant == 2 && !g_attn_force_tiled) {
+  if constexpr (DH <= 96) if ((g_attn_variant == 2 || g_attn_variant == 3) && !g_attn_force_tiled) {
     constexpr size_t lds = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG;
     static bool attr = false;
     if (int rc = allow_lds_bytes(attn_fwd_st_kernel<DH>, &attr, lds)) return rc;
@@ -1518,7 +1522,7 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
 }
 template <int DH>
 int bwd_t(const AttnParams& p, hipStream_t s) {
-  if constexpr (DH <= 96) if (g_attn_variant == 2 && !g_attn_force_tiled) {
+  if constexpr (DH <= 96) if ((g_attn_variant == 2 || g_attn_variant == 4) && !g_attn_force_tiled) {
     constexpr size_t lds1 = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG, lds2 = (size_t)SG<DH>::NSLOT * (2 * SG<DH>::IMG + 256);
     static bool attr1 = false, attr2 = false;
     if (int rc = allow_lds_bytes(attn_bwd_dq_st_kernel<DH>, &attr1, lds1)) return rc;

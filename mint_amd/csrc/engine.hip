@@ -262,6 +262,11 @@ struct FactHandle {
   int use_aux = 1;   // third stream for the motion stack's backward chain (0: on the caller's stream - the data-parallel
                      // trainer sets it: with its communication stream and RCCL's own the process would have more
                      // streams than the 4 hardware queues HIP gives it, and streams that share a queue serialise)
+  int grad_overwrite = 0;     // 1: a train step WRITES the gradient of every Dense kernel of a transformer layer (plain stores in the
+                              // grouped wgrad launch) instead of accumulating into it, and the optimizer pass does not zero those
+                              // ranges: 32 instead of 36 bytes per parameter and no read-modify-write in the wgrad epilogue.
+                              // The host trainer sets it (one forward_backward per optimizer step); the C-ABI default keeps the
+                              // accumulate semantics of fact_forward_backward.
   int skip = 0;               // TIMING-ONLY ablation mask (results are wrong): 1 wgrad 2 col sums 4 attn bwd 8 ln bwd 16 gelu' dgrad
                               // 32 ffn1 dgrad 64 qkv dgrad 128 out-proj dgrad 256 attn fwd 512 ln fwd
   int adam_hold = 1;          // in-backward optimizer: hold the head + cross buckets until the last is final
@@ -605,6 +610,11 @@ int build_buckets(FactHandle* h) {
   // Fused Adam + shadow refresh: walk every bucket's arena range; Dense kernels become 64x64 tile
   // blocks, everything between them (biases, LayerNorm, position tables, alignment padding) flat blocks.
   std::vector<AdamBlock> ab;
+  // Dense kernels of transformer layers: their gradient is written (not accumulated) in overwrite mode
+  std::vector<size_t> layer_w;
+  for (Stack* st : {&h->cross, &h->audio, &h->motion})
+    for (LayerP& p : st->lp)
+      for (DenseW* w : {&p.wqkv, &p.wo, &p.w1, &p.w2}) layer_w.push_back(w->w.off);
   for (Bucket& b : h->buckets) {
     b.blk_first = (int)ab.size();
     std::vector<CastDesc> ds(t.begin() + b.desc_first, t.begin() + b.desc_first + b.desc_n);
@@ -622,12 +632,14 @@ int build_buckets(FactHandle* h) {
     for (const CastDesc& d : ds) {
       const size_t toff = (size_t)(d.src - h->params);
       if (toff > cur) flat(cur, toff);
+      const int tw = adam_tile_width();
       for (int r0 = 0; r0 < d.R; r0 += 64)
-        for (int c0 = 0; c0 < d.C; c0 += 64) {
+        for (int c0 = 0; c0 < d.C; c0 += tw) {
           AdamBlock k;
           memset(&k, 0, sizeof(k));
           k.off = toff; k.s = d.s; k.t = d.t; k.R = d.R; k.C = d.C; k.lds = d.lds; k.ldt = d.ldt;
           k.r0 = r0; k.c0 = c0;
+          k.pad[0] = std::find(layer_w.begin(), layer_w.end(), toff) != layer_w.end() ? 1 : 0;
           ab.push_back(k);
         }
       // the tail of a Dense tensor whose size is not a multiple of 4 floats is covered by its tile
@@ -659,7 +671,7 @@ int adam_bucket(FactHandle* h, int b, hipStream_t s, const bf16_t* g16 = nullptr
   KScope ks(h, KP_ADAM, s, 0, (double)k.cnt * (g16 ? 34.0 : 36.0));
   if (h->fuse_adam_cast)
     return launch_adam_fused(h->adam_blocks + k.blk_first, k.blk_n, h->params, h->adam_m, h->adam_v, h->grads,
-                             a.lr_t, a.b1, a.b2, a.eps, a.gscale, s, g16);
+                             a.lr_t, a.b1, a.b2, a.eps, a.gscale, s, g16, h->grad_overwrite);
   if (g16) return fail(-1, "bf16 gradient source needs the fused Adam + shadow kernel");
   CHK(launch_adam(h->params + k.off, h->adam_m + k.off, h->adam_v + k.off, h->grads + k.off, k.cnt, a.lr_t,
                   a.b1, a.b2, a.eps, a.gscale, s));
@@ -738,6 +750,14 @@ int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int 
   return launch_gemm_nt(EPI_ATOMIC_F32, p, s);
 }
 
+// Per-GEMM fallback for a layer's Dense kernel: these kernels accumulate, so in overwrite mode (grad_overwrite: the
+// optimizer no longer zeroes the range) the target is cleared first.
+int wgrad_layer_tensor(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int ldb, int No, int K,
+                       float* out, int ldo, hipStream_t s, float* slab = nullptr) {
+  if (h->grad_overwrite) HIPCHK(hipMemsetAsync(out, 0, (size_t)Mo * No * sizeof(float), s));
+  return wgrad(h, A, lda, Mo, B, ldb, No, K, out, ldo, s, slab);
+}
+
 // The four weight gradients of one transformer layer as ONE grouped whole-K launch (gemm_big.hip): 160x256
 // tiles, the d-wide operand on the 160-tiled side (d = 800 -> 5 tiles exactly); dW2 = g^T dY is computed as
 // (dY^T g) and stored transposed.  Returns 1 when the shape is not eligible (caller takes the per-GEMM path).
@@ -758,6 +778,7 @@ int wgrad_layer_group(FactHandle* h, const Stack& st, const LayerP& p, const Lay
   set(1, a.h2, st.dp, d, dpre, st.fp, ff, G(h, p.w1.w), ff, 0);         // dW1[d][ff]  = LN2(x)^T dpre
   set(2, a.a, st.dp, d, xmid16, st.dp, d, G(h, p.wo.w), d, 0);          // dWo[d][d]   = attn^T dx_mid
   set(3, a.h1, st.dp, d, dqkv, st.qp, 3 * d, G(h, p.wqkv.w), 3 * d, 0); // dWqkv[d][3d] = LN1(x)^T dqkv
+  g.overwrite = h->grad_overwrite;
   CHK(launch_big_tn_group(g, s, h->wgrad_parts));
   return 0;
 }
@@ -942,17 +963,19 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
         set(0, r.dx16_c, dp, d, r.g_c, fp, ff, G(h, p.w2.w), d, 1);
         set(1, r.h2_c, dp, d, r.dpre_c, fp, ff, G(h, p.w1.w), ff, 0);
         set(2, r.a_c, dp, d, r.xmid16_c, dp, d, G(h, p.wo.w), d, 0);
+        g.overwrite = h->grad_overwrite;
         CHK(launch_big_tn_group(g, w, 1));
         memset(&g, 0, sizeof(g));
         g.n = 1;
         g.K = M;
         set(0, a.h1, dp, d, b.dqkv, qp, 3 * d, G(h, p.wqkv.w), 3 * d, 0);
+        g.overwrite = h->grad_overwrite;
         CHK(launch_big_tn_group(g, w, 1));
       } else {
-        CHK(wgrad(h, r.g_c, fp, ff, r.dx16_c, dp, d, Kc, G(h, p.w2.w), d, w, b.slab));
-        CHK(wgrad(h, r.h2_c, dp, d, r.dpre_c, fp, ff, Kc, G(h, p.w1.w), ff, w, b.slab));
-        CHK(wgrad(h, r.a_c, dp, d, r.xmid16_c, dp, d, Kc, G(h, p.wo.w), d, w, b.slab));
-        CHK(wgrad(h, a.h1, dp, d, b.dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w, b.slab));
+        CHK(wgrad_layer_tensor(h, r.g_c, fp, ff, r.dx16_c, dp, d, Kc, G(h, p.w2.w), d, w, b.slab));
+        CHK(wgrad_layer_tensor(h, r.h2_c, dp, d, r.dpre_c, fp, ff, Kc, G(h, p.w1.w), ff, w, b.slab));
+        CHK(wgrad_layer_tensor(h, r.a_c, dp, d, r.xmid16_c, dp, d, Kc, G(h, p.wo.w), d, w, b.slab));
+        CHK(wgrad_layer_tensor(h, a.h1, dp, d, b.dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w, b.slab));
       }
     }
     {
@@ -983,10 +1006,10 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
     const int rc = (h->skip & 1) ? 0 : wgrad_layer_group(h, st, p, a, b.xin16, b.dpre, b.xmid16, b.dqkv, M, w);
     if (rc < 0) return rc;
     if (rc > 0) {
-      CHK(wgrad(h, a.g, fp, ff, b.xin16, dp, d, M, G(h, p.w2.w), d, w, b.slab));
-      CHK(wgrad(h, a.h2, dp, d, b.dpre, fp, ff, M, G(h, p.w1.w), ff, w, b.slab));
-      CHK(wgrad(h, a.a, dp, d, b.xmid16, dp, d, M, G(h, p.wo.w), d, w, b.slab));
-      CHK(wgrad(h, a.h1, dp, d, b.dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w, b.slab));
+      CHK(wgrad_layer_tensor(h, a.g, fp, ff, b.xin16, dp, d, M, G(h, p.w2.w), d, w, b.slab));
+      CHK(wgrad_layer_tensor(h, a.h2, dp, d, b.dpre, fp, ff, M, G(h, p.w1.w), ff, w, b.slab));
+      CHK(wgrad_layer_tensor(h, a.a, dp, d, b.xmid16, dp, d, M, G(h, p.wo.w), d, w, b.slab));
+      CHK(wgrad_layer_tensor(h, a.h1, dp, d, b.dqkv, qp, 3 * d, M, G(h, p.wqkv.w), 3 * d, w, b.slab));
     }
   }
   // the HBM-bound column sums share CUs with anything: their own stream, so they run beside the wgrad launches
@@ -1543,6 +1566,14 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     h->use_lite = value;
     return 0;
   }
+  if (!strcmp(key, "adam_variant")) {  // process-wide: optimizer kernel (rowops.hip launch_adam_fused)
+    adam_set_variant(value);
+    return 0;
+  }
+  if (!strcmp(key, "grad_overwrite")) {
+    h->grad_overwrite = value;
+    return 0;
+  }
   if (!strcmp(key, "skip")) {
     h->skip = value;
     return 0;
@@ -1747,7 +1778,7 @@ int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps,
   if (h->fuse_adam_cast && !h->buckets.empty()) {
     const Bucket& last = h->buckets.back();
     return launch_adam_fused(h->adam_blocks, last.blk_first + last.blk_n, h->params, h->adam_m, h->adam_v,
-                             h->grads, (float)lr_t, beta1, beta2, eps, gscale, s);
+                             h->grads, (float)lr_t, beta1, beta2, eps, gscale, s, nullptr, h->grad_overwrite);
   }
   CHK(launch_adam(h->params, h->adam_m, h->adam_v, h->grads, h->arena_floats, (float)lr_t, beta1, beta2,
                   eps, gscale, s));

@@ -90,6 +90,7 @@ struct TnGroup {
   int n;
   int K;
   int tile0;  // first logical tile of this launch (filled by the launcher)
+  int overwrite;  // 1: out = product (plain stores; every output element belongs to exactly one tile), 0: out += product
 };
 // `parts` > 1 cuts the group's tiles into that many launches (same stream, in order) of about equal size: each
 // then occupies only ~tiles/parts CUs, which leaves room for the CU-exclusive kernels of another stream.

@@ -945,7 +945,8 @@ __global__ __launch_bounds__(C::NW * 64, 1) void big_tn_kernel(const TnGroup g) 
       for (int j = 0; j < NR; ++j) {
         const int n = ncol[j] + (lane >> 4) * 4;
         old[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < pr.M && n + 3 < pr.N) old[i][j] = *reinterpret_cast<const float4*>(pr.out + (size_t)m * pr.ldo + n);
+        if (!g.overwrite && m < pr.M && n + 3 < pr.N)
+          old[i][j] = *reinterpret_cast<const float4*>(pr.out + (size_t)m * pr.ldo + n);
       }
     }
 #pragma unroll
@@ -972,7 +973,8 @@ __global__ __launch_bounds__(C::NW * 64, 1) void big_tn_kernel(const TnGroup g) 
       for (int j = 0; j < NR; ++j) {
         const int n = ncol[j] + (lane & 15);
         old[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < pr.N && m + 3 < pr.M) old[i][j] = *reinterpret_cast<const float4*>(pr.out + (size_t)n * pr.ldo + m);
+        if (!g.overwrite && n < pr.N && m + 3 < pr.M)
+          old[i][j] = *reinterpret_cast<const float4*>(pr.out + (size_t)n * pr.ldo + m);
       }
     }
 #pragma unroll

@@ -93,7 +93,12 @@ struct AdamBlock {
 // the data-parallel path) instead of from `g`; `g` is still zeroed.
 int launch_adam_fused(const AdamBlock* blocks, int nblocks, float* p, float* m, float* v, float* g,
                       float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s,
-                      const bf16_t* g16 = nullptr);
+                      const bf16_t* g16 = nullptr, int keep_overwritten = 0);
+// `keep_overwritten`: blocks flagged AdamBlock::pad[0] & 1 (Dense kernels whose gradient the next step's wgrad launch
+// overwrites) are not zeroed.
+
+void adam_set_variant(int v);  // 0 round-2 kernel, 1 round-3 kernel, 2 round-3 kernel with non-temporal accesses
+int adam_tile_width();         // 64 or 128 (FACT_ADAM_TW): column width of the dense AdamBlock tiles
 
 // f32 [R][C] -> bf16 dst [R][ldd] and bf16 dstT [C][ldt] (either may be null)
 int launch_cast_transpose(const float* src, int R, int C, bf16_t* dst, int ldd, bf16_t* dstT, int ldt,

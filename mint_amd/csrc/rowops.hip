@@ -2,6 +2,8 @@
 // LayerNorm kernels: float4 loads, wave-shuffle reductions, no LDS in the row statistics.
 #include "rowops.h"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int LN_MAXV = 8;  // float4 vectors per lane -> C <= 2048
@@ -591,6 +593,130 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(const AdamBlock* __rest
   }
 }
 
+// Round 3: the same pass with (a) non-temporal loads / stores on the four fp32 streams (each byte is touched once per
+// step), (b) every load of a group of row passes issued before the first use, (c) 64 x TW tiles (TW = 64 or 128: 256- or
+// 512-byte row runs) and (d) no zero write-back of the gradient where the block says its producer overwrites it
+// (AdamBlock::pad[0] & 1: Dense kernels whose weight gradient comes from the whole-K grouped wgrad launch, engine option
+// grad_overwrite).  tools/adam_probe.hip: a flat kernel with today's access mix streams 5.85 TB/s, 6.3 with non-temporal
+// accesses, and the 32 B/param mix (no zeroing) finishes in 0.63-0.64 ms against 0.74 for 36 B/param.
+DEVINL f32x4 ld4(const float* p, bool nt) {
+  return nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)) : *reinterpret_cast<const f32x4*>(p);
+}
+DEVINL void st4(float* p, f32x4 v, bool nt) {
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<f32x4*>(p) = v;
+}
+template <int TW, bool NT>
+__global__ __launch_bounds__(256) void adam_fused2_kernel(const AdamBlock* __restrict__ blocks, float* __restrict__ P,
+                                                          float* __restrict__ Mm, float* __restrict__ V,
+                                                          float* __restrict__ G, const bf16_t* __restrict__ G16,
+                                                          float lr_t, float b1, float b2, float eps, float gscale,
+                                                          int honor_keep) {
+  __shared__ float tile[64][TW + 1];
+  const AdamBlock d = blocks[blockIdx.x];
+  const bool keep_g = honor_keep && (d.pad[0] & 1) != 0;
+  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  auto grad4 = [&](size_t o) -> f32x4 {
+    if (G16) {
+      const bf16x4 g = *reinterpret_cast<const bf16x4*>(G16 + o);
+      return f32x4{(float)g[0], (float)g[1], (float)g[2], (float)g[3]};
+    }
+    return ld4(G + o, NT);
+  };
+  auto upd4 = [&](f32x4& pv, f32x4& mv, f32x4& vv, f32x4 gv) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float pj = pv[j], mj = mv[j], vj = vv[j];
+      adam1(pj, mj, vj, gv[j] * gscale, lr_t, b1, b2, eps);
+      pv[j] = pj; mv[j] = mj; vv[j] = vj;
+    }
+  };
+  if (d.R == 0) {  // flat segment (<= 4096 floats): biases, LayerNorm, tables, padding - always zeroed (atomics feed them)
+    for (int i = threadIdx.x * 4; i < d.C; i += 1024) {
+      const size_t o = d.off + i;
+      f32x4 gv = grad4(o), mv = ld4(Mm + o, NT), vv = ld4(V + o, NT), pv = ld4(P + o, NT);
+      upd4(pv, mv, vv, gv);
+      st4(P + o, pv, NT); st4(Mm + o, mv, NT); st4(V + o, vv, NT); st4(G + o, z, NT);
+    }
+    return;
+  }
+  constexpr int CQ = TW / 4, RP = 256 / CQ, NPASS = 64 / RP, GRP = 4;  // column quads per row, rows per pass, passes
+  static_assert(NPASS % GRP == 0, "pass groups");
+  const int cx = (threadIdx.x % CQ) * 4, ry = threadIdx.x / CQ;
+  const bool vec_ok = ((d.C & 3) == 0);
+  if (vec_ok) {
+#pragma unroll
+    for (int g0 = 0; g0 < NPASS; g0 += GRP) {
+      f32x4 gv[GRP], mv[GRP], vv[GRP], pv[GRP];
+      bool ok[GRP];
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int r = d.r0 + ry + (g0 + u) * RP, c = d.c0 + cx;
+        ok[u] = r < d.R && c + 3 < d.C;
+        if (ok[u]) {
+          const size_t o = d.off + (size_t)r * d.C + c;
+          gv[u] = grad4(o); mv[u] = ld4(Mm + o, NT); vv[u] = ld4(V + o, NT); pv[u] = ld4(P + o, NT);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < GRP; ++u) {
+        const int rr = ry + (g0 + u) * RP;
+        f32x4 w = z;
+        if (ok[u]) {
+          const int r = d.r0 + rr, c = d.c0 + cx;
+          const size_t o = d.off + (size_t)r * d.C + c;
+          upd4(pv[u], mv[u], vv[u], gv[u]);
+          st4(P + o, pv[u], NT); st4(Mm + o, mv[u], NT); st4(V + o, vv[u], NT);
+          if (!keep_g) st4(G + o, z, NT);
+          w = pv[u];
+          bf16x4 o16 = {(bf16_t)w[0], (bf16_t)w[1], (bf16_t)w[2], (bf16_t)w[3]};
+          *reinterpret_cast<bf16x4*>(d.s + (size_t)r * d.lds + c) = o16;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[rr][cx + j] = w[j];
+      }
+    }
+  } else {
+    for (int rr = ry; rr < 64; rr += RP) {
+      const int r = d.r0 + rr, c = d.c0 + cx;
+      float w[4] = {0.f, 0.f, 0.f, 0.f};
+      if (r < d.R) {
+        const size_t o = d.off + (size_t)r * d.C + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (c + j < d.C) {
+            float pv = P[o + j], mv = Mm[o + j], vv = V[o + j];
+            adam1(pv, mv, vv, (G16 ? (float)G16[o + j] : G[o + j]) * gscale, lr_t, b1, b2, eps);
+            P[o + j] = pv; Mm[o + j] = mv; V[o + j] = vv;
+            if (!keep_g) G[o + j] = 0.f;
+            w[j] = pv;
+            d.s[(size_t)r * d.lds + c + j] = (bf16_t)pv;
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[rr][cx + j] = w[j];
+    }
+  }
+  __syncthreads();
+  // transposed shadow: thread -> column cc, 4 consecutive rows (16 threads cover the 64 rows of a column = 128 bytes)
+  const int rq = (threadIdx.x & 15) * 4, cy = threadIdx.x >> 4;
+#pragma unroll
+  for (int cc = cy; cc < TW; cc += 16) {
+    const int c = d.c0 + cc, r = d.r0 + rq;
+    if (c < d.C) {
+      if (r + 3 < d.R) {
+        bf16x4 o = {(bf16_t)tile[rq][cc], (bf16_t)tile[rq + 1][cc], (bf16_t)tile[rq + 2][cc],
+                    (bf16_t)tile[rq + 3][cc]};
+        *reinterpret_cast<bf16x4*>(d.t + (size_t)c * d.ldt + r) = o;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (r + j < d.R) d.t[(size_t)c * d.ldt + r + j] = (bf16_t)tile[rq + j][cc];
+      }
+    }
+  }
+}
+
 // 64x64 tile cast/transpose through LDS
 template <typename T>
 __global__ __launch_bounds__(256) void cast_transpose_kernel(const T* __restrict__ src, int lds_,
@@ -937,12 +1063,43 @@ int launch_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, fl
   return 0;
 }
 
+int g_adam_variant = 1, g_adam_tw = 64;
 int launch_adam_fused(const AdamBlock* blocks, int nblocks, float* p, float* m, float* v, float* g,
-                      float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s, const bf16_t* g16) {
+                      float lr_t, float b1, float b2, float eps, float gscale, hipStream_t s, const bf16_t* g16,
+                      int keep) {
   if (nblocks <= 0) return 0;
-  hipLaunchKernelGGL(adam_fused_kernel, dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t, b1, b2, eps,
-                     gscale);
+  // g_adam_variant: 0 = round-2 kernel (64x64 tiles), 1 = round-3 kernel plain accesses, 2 = ... non-temporal;
+  // the tile width is a property of the block table (adam_tile_width()), fixed when the handle is created
+  if (g_adam_variant == 0 && g_adam_tw == 64 && !keep)
+    hipLaunchKernelGGL(adam_fused_kernel, dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t, b1, b2, eps,
+                       gscale);
+  else if (g_adam_tw == 128) {
+    if (g_adam_variant == 2)
+      hipLaunchKernelGGL((adam_fused2_kernel<128, true>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
+                         b1, b2, eps, gscale, keep);
+    else
+      hipLaunchKernelGGL((adam_fused2_kernel<128, false>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
+                         b1, b2, eps, gscale, keep);
+  } else {
+    if (g_adam_variant == 2)
+      hipLaunchKernelGGL((adam_fused2_kernel<64, true>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
+                         b1, b2, eps, gscale, keep);
+    else
+      hipLaunchKernelGGL((adam_fused2_kernel<64, false>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
+                         b1, b2, eps, gscale, keep);
+  }
   return 0;
+}
+void adam_set_variant(int v) { g_adam_variant = v; }
+int adam_tile_width() {
+  static bool once = false;
+  if (!once) {
+    const char* e = getenv("FACT_ADAM_TW");
+    if (e && atoi(e) == 128) g_adam_tw = 128;
+    if (e && atoi(e) == 64) g_adam_tw = 64;
+    once = true;
+  }
+  return g_adam_tw;
 }
 
 int launch_cast_transpose(const float* src, int R, int C, bf16_t* dst, int ldd, bf16_t* dstT, int ldt,

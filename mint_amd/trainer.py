@@ -199,6 +199,7 @@ class SingleTaskTrainer:
         else:
             self.metrics = [metrics]
         self._iter = None
+        self._grad_overwrite_set = False
         self._reducer = None
         self._bf16_buckets = bool(bf16_grad_buckets)
         if overlap_grad_allreduce is None:
@@ -233,6 +234,17 @@ class SingleTaskTrainer:
         R = self.num_replicas_in_sync
         if (self._overlap or self._fuse) and hasattr(self.model, "ensure_built"):
             self.model.ensure_built(inputs)
+        if not self._grad_overwrite_set and hasattr(self.model, "set_option"):
+            # one forward_backward per optimizer step: the layer weight gradients can be WRITTEN by the wgrad launches
+            # instead of accumulated, and the optimizer pass need not zero them (engine option grad_overwrite)
+            if hasattr(self.model, "ensure_built"):
+                self.model.ensure_built(inputs)
+            try:
+                import os
+                self.model.set_option("grad_overwrite", int(os.environ.get("FACT_GRAD_OVERWRITE", "1")))
+            except Exception:
+                pass
+            self._grad_overwrite_set = True
         if self._overlap and self._reducer is None:
             self._reducer = OverlappedGradReducer(self.model, bf16_buckets=self._bf16_buckets)
         # fused path: single replica without a gradient callback (the engine updates the buckets itself), or - with

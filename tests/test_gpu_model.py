@@ -15,6 +15,20 @@ from oracle import fact_oracle as O
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def continuous_attention():
+    """Equivalence tests that compare two IMPLEMENTATIONS of one computation at fp32 round-off tolerances (two Adam
+    kernels, two data-parallel optimizer placements) over several optimizer steps need a forward that is a continuous
+    function of the weights at that scale.  The default streaming forward kernel raises its running softmax maximum only
+    when a score outgrows it by more than 2^6 (exact by shift invariance, but the bf16 rounding of P is re-rolled whenever
+    a 1-ulp weight difference flips such a decision: 4e-9 -> 3e-3 relative output difference, measured); the LDS-resident
+    family has no such threshold."""
+    from mint_amd import _lib as L
+    L.lib().fact_debug_attn_variant(1)
+    yield
+    L.lib().fact_debug_attn_variant(3)
+
+
 def make_config(cfg):
     mm = protos.MultiModalModel()
     fm = mm.fact_model
@@ -377,7 +391,7 @@ def test_headline_batch_big_tile_path_matches_128_tile_path():
             assert rel(g0, g1) < 1e-2, "%s rel %.4f" % (name, rel(g0, g1))
 
 
-def test_overlapped_allreduce_callback_path_single_rank():
+def test_overlapped_allreduce_callback_path_single_rank(continuous_attention):
     """Bucket-ready callbacks + RCCL on a side stream (world_size 1 here: the multi-GPU path with the
     same code; the sum over one replica must leave gradients/updates identical to the plain path)."""
     import os
@@ -458,8 +472,13 @@ def test_overlapped_allreduce_callback_path_single_rank():
                 torch.cuda.synchronize()
                 assert tr._reducer.fused_adam == bool(mode)
                 assert tr.optimizer.iterations == 4 and m.global_step == 4
+                # what the optimizer pass still has to zero: every gradient that is ACCUMULATED into (atomics / split-K
+                # reduce).  The trainer runs with grad_overwrite = 1: the transformer-layer Dense kernels' gradients are
+                # plain-stored by the grouped wgrad launch of the next step and are left alone.
+                acc_max = max(float(g.abs().max()) for n, g in zip(m.variable_names, m.gradients)
+                              if not ("/layer_" in n and n.endswith("/kernel")))
                 outs.append((mode, bf16, ls, torch.cat([v.flatten() for v in m.trainable_variables]).cpu(),
-                             m._arena["adam_m"].cpu().clone(), float(m.grad_arena.abs().max())))
+                             m._arena["adam_m"].cpu().clone(), acc_max))
         for bf16 in (False, True):
             a = [o for o in outs if o[1] == bf16 and o[0] is False][0]
             b = [o for o in outs if o[1] == bf16 and o[0] == "force"][0]
@@ -470,7 +489,7 @@ def test_overlapped_allreduce_callback_path_single_rank():
             assert float(du) < 2e-2, float(du)
             assert float((a[3] - b[3]).abs().max()) <= 2.5 * 1e-3 * 4
             assert float((a[4] - b[4]).norm() / a[4].norm()) < 1e-3
-            assert b[5] == 0.0, "gradients not zeroed by the per-bucket optimizer step"
+            assert a[5] == 0.0 and b[5] == 0.0, "accumulated gradients not zeroed by the optimizer step"
     finally:
         dist.destroy_process_group()
 
@@ -537,7 +556,7 @@ def test_checkpoint_resume_and_evaluator_on_engine(tmp_path):
     np.testing.assert_allclose(a[:32], batch["motion_input"][0].cpu().numpy())
 
 
-def test_fused_optimizer_in_backward_matches_separate_step():
+def test_fused_optimizer_in_backward_matches_separate_step(continuous_attention):
     """fact_adam_begin + per-bucket Adam on the optimizer stream inside backward == forward_backward
     followed by fact_adam_step (same kernels, same arithmetic, different scheduling)."""
     cfg = O.TINY_CFG
@@ -550,14 +569,17 @@ def test_fused_optimizer_in_backward_matches_separate_step():
         losses = [float(tr.train_step(it)) for _ in range(4)]
         torch.cuda.synchronize()
         assert tr.optimizer.iterations == 4 and model.global_step == 4
-        assert float(model.grad_arena.abs().max()) == 0.0  # every bucket consumed and zeroed
+        # every bucket consumed; what is accumulated into (atomics / split-K reduce) is zeroed again - the layer Dense
+        # kernels' gradients are overwritten by the next step's wgrad launches (grad_overwrite, set by the trainer)
+        assert max(float(g.abs().max()) for n, g in zip(model.variable_names, model.gradients)
+                   if not ("/layer_" in n and n.endswith("/kernel"))) == 0.0
         finals.append((losses, torch.cat([v.flatten() for v in model.trainable_variables]).cpu()))
     assert finals[0][0] == pytest.approx(finals[1][0], rel=1e-6)
     assert torch.allclose(finals[0][1], finals[1][1], rtol=1e-5, atol=1e-7)
 
 
 @pytest.mark.parametrize("fused_step", [False, True])
-def test_adam_fused_with_shadow_refresh_matches_two_kernel_path(fused_step):
+def test_adam_fused_with_shadow_refresh_matches_two_kernel_path(fused_step, continuous_attention):
     """The fused Adam + bf16-shadow kernel (one pass over p/m/v/g that also writes both weight shadows)
     against the two-kernel path (flat Adam, then cast/transpose): same per-element arithmetic (up to fma
     contraction and the atomic order of the bias/LayerNorm gradient sums), so master weights, both
@@ -583,8 +605,15 @@ def test_adam_fused_with_shadow_refresh_matches_two_kernel_path(fused_step):
         finals.append((out.cpu(), {k: v.clone().cpu() for k, v in st.items() if torch.is_tensor(v)}))
     assert (finals[0][0] - finals[1][0]).norm() / finals[0][0].norm() < 2e-3
     for k in finals[0][1]:
+        if k == "grads":  # the flat two-kernel Adam zeroes everything, the fused one keeps what the next wgrad overwrites
+            continue
         assert torch.allclose(finals[0][1][k], finals[1][1][k], rtol=1e-5, atol=1e-7), k
-    assert float(finals[1][1]["grads"].abs().max()) == 0.0
+    names = O.param_shapes(cfg)
+    off = 0  # (arena offsets are 64-float aligned: walk the table instead of assuming a packed layout)
+    model_tab = model._table
+    g_final = finals[1][1]["grads"]
+    assert max(float(g_final[o:o + r * c].abs().max()) for (n, o, r, c, _k) in model_tab
+               if not ("/layer_" in n and n.endswith("/kernel"))) == 0.0
 
 
 def test_ragged_lengths_second_step_grads():
