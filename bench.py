@@ -74,6 +74,11 @@ def parse():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo = DRY RUN of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share "
                          "devices, the collective goes through the host): the timing means nothing")
+    ap.add_argument("--dp-aux-stream", type=int, default=0,
+                    help="N > 1: 1 = keep the engine's third stream (motion-encoder backward chain) under data parallelism. "
+                         "Default 0: with the communication stream and RCCL's own the process then stays at <= 6 busy "
+                         "hardware queues (GPU_MAX_HW_QUEUES = 7; an 8th busy queue doubled the step in the one-GPU dry "
+                         "run, profiles/r02_dp_dry_run.txt) at ~0.2 ms per step")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="engine option for A/B runs (fact_set_option), e.g. --opt wgrad_parts=1")
     return ap.parse_args()
@@ -82,19 +87,26 @@ def parse():
 PEAK_HBM_GBS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
 # kernel symbols behind each class of the engine's in-step table (for matching against rocprofv3 summaries)
 KERNEL_SYMBOLS = {
-    "wgrad_group": "big_tn_kernel<BigCfg<2,5,4,4>> (160x256 whole-K tiles, grouped: 4 wgrads of a layer)",
-    "ffn1+gelu": "big_nt_kernel<BigCfg<2,9,4,4>, EPI_BIAS_GELU> (288x256 tiles)",
-    "gelu'_dgrad": "big_nt_kernel<BigCfg<2,9,4,4>, EPI_GELU_BWD> (288x256 tiles)",
-    "qkv_gemm+heads": "big_nt_kernel<BigCfg<2,8,4,4>, EPI_HEADS> (256x256 tiles)",
-    "ffn2+resid": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_F32_BIAS_RESID> (256x160 tiles, in-kernel split-K)",
-    "out_proj+resid": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_F32_BIAS_RESID> (256x160 tiles)",
-    "ffn1_dgrad": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_BF16> (256x160 tiles)",
-    "qkv_dgrad": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_BF16> (256x160 tiles)",
-    "out_proj_dgrad+heads": "big_nt_kernel<BigCfg<4,4,2,5>, EPI_HEADS> (256x160 tiles)",
-    "attention_fwd": "attn_fwd_res_kernel<80>", "attention_bwd": "attn_bwd_dq_res_kernel<80> + attn_bwd_dkdv_res_kernel<80>",
-    "ln_fwd": "ln_fwd_kernel", "ln_bwd_dx": "ln_bwd_dx_kernel", "bias/ln_param_grads": "colsum_kernel + ln_param_grads_kernel",
-    "adam+shadows": "adam_fused_kernel",
+    "wgrad_group": "big_tn_kernel<BigCfg<2,5,4,4,4,1>, 0> (160x256 whole-K tiles, grouped: 4 wgrads of a layer, 2 launches of 95)",
+    "ffn1+gelu": "big_nt_kernel<BigCfg<2,9,4,4,4,1>, EPI_BIAS_GELU> (288x256 tiles)",
+    "gelu'_dgrad": "big_nt_kernel<BigCfg<2,9,4,4,4,1>, EPI_GELU_BWD> (288x256 tiles)",
+    "qkv_gemm+heads": "big_nt_kernel<BigCfg<2,8,4,4,4,1>, EPI_HEADS> (256x256 tiles)",
+    "ffn2+resid": "big_nt_kernel<BigCfg<4,4,2,5,4,1>, EPI_F32_BIAS_RESID> (256x160 tiles, in-kernel split-K 2)",
+    "out_proj+resid": "big_nt_kernel<BigCfg<4,4,2,4,3,2>, EPI_F32_BIAS_RESID> (256x128 tiles, 2 workgroups per CU)",
+    "ffn1_dgrad": "big_nt_kernel<BigCfg<4,4,2,5,4,1>, EPI_BF16> (256x160 tiles, whole K)",
+    "qkv_dgrad": "big_nt_kernel<BigCfg<4,4,2,5,4,1>, EPI_BF16> (256x160 tiles, whole K)",
+    "out_proj_dgrad+heads": "big_nt_kernel<BigCfg<4,4,2,4,3,2>, EPI_HEADS> (256x128 tiles, 2 workgroups per CU)",
+    "attention_fwd": "attn_fwd_st_kernel<80> (streaming, 480 workgroups)",
+    "attention_bwd": "attn_bwd_dq_res_kernel<80> + attn_bwd_dkdv_res_kernel<80> (LDS-resident, 160 workgroups each)",
+    "ln_fwd": "ln_fwd_kernel", "ln_bwd_dx": "ln_bwd_dx_kernel<4>", "bias/ln_param_grads": "col_tasks_kernel",
+    "adam+shadows": "adam_fused2_kernel<64,false>",
 }
+# CUs a launch of the class can hold at fact_v5 / B = 16 (workgroups of the cross-modal launch, capped at 256; big-tile
+# kernels run one workgroup per CU, the 256x128 config two): the whole-chip `frac` of a class that is deliberately
+# given part of the chip understates the kernel - `frac_of_held_cus` = frac / cu_share is the per-CU figure
+CLASS_CUS = {"wgrad_group": 95, "ffn1+gelu": 240, "gelu'_dgrad": 240, "qkv_gemm+heads": 230, "ffn2+resid": 230,
+             "out_proj+resid": 81, "ffn1_dgrad": 115, "qkv_dgrad": 115, "out_proj_dgrad+heads": 81,
+             "attention_fwd": 256, "attention_bwd": 160}
 
 
 def kernel_table(model, step_fn, nsteps):
@@ -121,6 +133,9 @@ def kernel_table(model, step_fn, nsteps):
             tf = r["flops"] / (r["total_ms"] * 1e-3) / 1e12
             row.update(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                        frac=round(tf / PEAK_BF16_TFLOPS, 4), flop_per_launch=r["flops"] / r["launches"])
+            if r["name"] in CLASS_CUS:
+                share = CLASS_CUS[r["name"]] / 256.0
+                row.update(cu_share=round(share, 3), frac_of_held_cus=round(tf / PEAK_BF16_TFLOPS / share, 4))
         else:
             gbs = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
             row.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
@@ -197,7 +212,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(B=4, timed=2, budget_s=10.0, max_timed=16):
+def cpu_baseline(B=4, timed=2, budget_s=10.0, max_timed=16, b16_check=True):
     """Oracle (PyTorch-CPU fp32 restatement of the reference train step: forward, loss, backward, Keras Adam)
     on a bounded sample of the same workload: fact_v5 at batch 4 (a quarter of the per-GPU batch; the fp32 GEMMs
     of the oracle are large enough at 1440 tokens that frames/s does not depend on the batch), 1 warm-up step
@@ -223,9 +238,19 @@ def cpu_baseline(B=4, timed=2, budget_s=10.0, max_timed=16):
             params, m, v = _oracle_step(O, params, m, v, step + 1 + n, cfg, batch)
             n += 1
         dt, note = time.perf_counter() - t0, "1 warm-up + %d timed train steps" % n
-    return {"value": round(n * B * 120 / dt, 2), "unit": "motion frames/sec", "cores": cores, "kind": "port",
-            "sample": "%s of fact_v5 at batch %d (%.1f s timed; fp32 PyTorch-CPU oracle, %d threads)" % (
-                note, B, dt, cores)}
+    out = {"value": round(n * B * 120 / dt, 2), "unit": "motion frames/sec", "cores": cores, "kind": "port",
+           "sample": "%s of fact_v5 at batch %d (%.1f s timed; fp32 PyTorch-CPU oracle, %d threads)" % (
+               note, B, dt, cores)}
+    if b16_check and t_warm <= 20.0:
+        # SURVEY 8(d) names the per-GPU batch of 16: ONE cold step at that batch beside the bounded batch-4 sample
+        batch16 = O.synthetic_batch(cfg, 16, TARGET_LEN, seed=1, dtype=torch.float32)
+        t0 = time.perf_counter()
+        _oracle_step(O, params, m, v, step + 1 + n, cfg, batch16)
+        t16 = time.perf_counter() - t0
+        out["batch16_one_step"] = {"seconds": round(t16, 2), "frames_per_sec": round(16 * 120 / t16, 2),
+                                   "note": "one un-warmed train step at the per-GPU batch of 16 (first touch of the batch-16 "
+                                           "activations included)"}
+    return out
 
 
 def _oracle_step(O, params, m, v, step, cfg, batch):
@@ -411,6 +436,8 @@ def main():
              "target": torch.randn(B, TARGET_LEN, 225, generator=gen).to(device)}
     model.build(B, 225, 35)
     model.set_option("side_stream", args.side_stream)
+    if world > 1 and not args.dp_aux_stream:
+        model.set_option("aux_stream", 0)
     for kv in args.opt:
         k, v = kv.split("=")
         model.set_option(k, int(v))
@@ -469,6 +496,14 @@ def main():
             file=sys.stderr)
 
     rows, ksum_ms = kernel_table(model, lambda: trainer.train_step(it), max(1, args.profile_steps))
+    comm = None
+    if world > 1 and getattr(trainer, "_reducer", None) is not None:
+        # per-bucket all-reduce time and exposed communication (diagnosis of a bad scaling record; after the timed region)
+        trainer._reducer.profile = True
+        for _ in range(max(1, args.profile_steps)):
+            trainer.train_step(it)
+        comm = trainer._reducer.comm_report()
+        trainer._reducer.profile = False
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         frames_per_s = world * B * 120 / (dt / args.steps)
@@ -492,6 +527,8 @@ def main():
                                     / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
         }
+        if comm is not None:
+            out["comm"] = comm
         if dry:
             out["dry_run"] = "gloo, ranks sharing devices: control-flow check of the N > 1 path, not a measurement"
         out["kernels"] = rows
@@ -501,7 +538,8 @@ def main():
                            "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
                            "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"],
                            "time_share": top["time_share"],
-                           "flop_per_launch": top.get("flop_per_launch"), "traffic": traffic, "traffic_source": src,
+                           "flop_per_launch": top.get("flop_per_launch"), "cu_share": top.get("cu_share"),
+                           "frac_of_held_cus": top.get("frac_of_held_cus"), "traffic": traffic, "traffic_source": src,
                            "how": "HIP events on the launch stream around every launch of the class, inside normal "
                                   "train steps (all streams overlapping); sum of kernel-class time per step "
                                   "%.2f ms vs %.2f ms wall" % (ksum_ms, ms_per_step)}

@@ -113,6 +113,11 @@ class OverlappedGradReducer:
         self.fused_adam = False  # set per step by the trainer
         self._buf16 = None
         self.buckets_seen = []   # (bucket, offset, count) of the step in flight, in arrival order
+        # diagnostics (bench.py --gpus N): with `profile` on, every bucket's all-reduce is bracketed by events on the
+        # communication stream and finish() by events on the compute stream; read with `comm_report()`
+        self.profile = False
+        self._prof = []          # (bucket, count, event before, event after) of profiled steps
+        self._prof_finish = []   # (event before finish, event after) per profiled step
         model.set_grad_callback(self._on_bucket, self.comm)
         # This stream and RCCL's own join the engine's three: more streams than the 4 hardware queues HIP uses by
         # default, and streams that share a queue serialise (one-GPU dry run with RCCL initialised, tools/dp_probe.py:
@@ -138,10 +143,15 @@ class OverlappedGradReducer:
                     self._buf16 = torch.empty(arena.numel(), dtype=torch.bfloat16, device=arena.device)
                 buf = self._buf16[offset:offset + count]
                 self.model.cast_bucket_to_bf16(arena[offset:offset + count], buf, self.comm)
+                e0 = self._mark()
                 w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
             else:
                 buf = None
+                e0 = self._mark()
                 w = dist.all_reduce(arena[offset:offset + count], op=dist.ReduceOp.SUM, async_op=True)
+            if e0 is not None:
+                w.wait()  # profiling: the communication stream waits here, so the closing event times the collective
+                self._prof.append((bucket, count, e0, self._mark()))
             if self.fused_adam:
                 # optimizer step of this bucket right behind its all-reduce, on the communication stream: the
                 # HBM-bound update overlaps the rest of backward instead of following it as one serial pass
@@ -153,7 +163,43 @@ class OverlappedGradReducer:
             else:
                 self.works.append((w, offset, count, buf))
 
+    def _mark(self):
+        if not (self.profile and self.comm is not None):
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(self.comm)
+        return e
+
+    def comm_report(self):
+        """Per-bucket all-reduce time and the time the compute stream spent in finish() (= communication that backward
+        did not hide, plus the bf16 cast-back when Adam is not fused), averaged over the profiled steps."""
+        if not self._prof:
+            return None
+        torch.cuda.synchronize()
+        per, steps = {}, max(1, len(self._prof_finish))
+        for bucket, count, e0, e1 in self._prof:
+            d = per.setdefault(bucket, {"bucket": bucket, "MB": round(count * (2 if self.bf16 else 4) / 1e6, 2), "ms": 0.0, "n": 0})
+            d["ms"] += e0.elapsed_time(e1)
+            d["n"] += 1
+        rows = [{"bucket": d["bucket"], "MB": d["MB"], "allreduce_ms": round(d["ms"] / d["n"], 3)} for d in per.values()]
+        exposed = sum(a.elapsed_time(b) for a, b in self._prof_finish) / steps
+        return {"buckets": rows, "allreduce_ms_per_step": round(sum(r["allreduce_ms"] for r in rows), 3),
+                "exposed_ms_per_step": round(exposed, 3), "profiled_steps": steps,
+                "payload": "bf16" if self.bf16 else "fp32"}
+
     def finish(self):
+        if self.profile and torch.cuda.is_available():
+            a = torch.cuda.Event(enable_timing=True)
+            a.record()
+        else:
+            a = None
+        self._finish()
+        if a is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record()
+            self._prof_finish.append((a, b))
+
+    def _finish(self):
         arena = self.model.grad_arena
         for w, offset, count, buf in self.works:
             if buf is None:
