@@ -229,6 +229,8 @@ int fact_debug_attn_variant(int v);
 /* Bench only: device buffer of u64[B*H][waves][8] that receives per-wave s_memtime stamps of the LDS-resident
  * forward attention kernel (null = off). */
 int fact_debug_attn_timestamps(void* buf);
+/* bench only: `nwg` one-per-CU workgroups that spin for ~`micros` microseconds on `stream` (CU-availability probe) */
+int fact_debug_cu_hog(int nwg, int micros, void* stream);
 /* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 6 / 7 = big-tile 288x256 / 256x256). */
 int fact_debug_gemm_splitk_max(int v); /* in-kernel split-K slices of the N = 800 GEMMs (1 = off, default 4) */
 int fact_debug_gemm_tn_cfg(int v); /* grouped wgrad tile: 0 = 160x256, 1 = 160x384 */

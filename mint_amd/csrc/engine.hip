@@ -2167,6 +2167,42 @@ int fact_debug_attn_force_tiled(int on) {
   attn_set_force_tiled(on);
   return 0;
 }
+// Occupies `nwg` CUs for ~`micros` microseconds: one 256-thread workgroup per CU (96 KiB of LDS each keeps a second one
+// off the CU), spinning on the shader clock.  Stand-in for a communication kernel that holds CUs while the step runs
+// (tools/cu_hog_probe.py: what does the train step lose when N CUs are not available to it?).
+__global__ __launch_bounds__(256) void cu_hog_kernel(long long cycles, unsigned* sink, int mode) {
+  extern __shared__ unsigned char hog_lds[];
+  unsigned acc = 0;
+  if (mode & 2) {  // no clock polling: a counted sleep loop (~64 * 64 cycles per trip at the shader clock)
+    for (long long i = 0; i < cycles / 2; ++i) {
+      __builtin_amdgcn_s_sleep(64);
+      asm volatile("" : "+v"(acc));
+    }
+  } else {
+    const long long t0 = (long long)wall_clock64();  // constant 100 MHz counter (s_memrealtime)
+    while ((long long)wall_clock64() - t0 < cycles) {
+      if (!(mode & 1)) acc += hog_lds[(threadIdx.x * 64) & 1023];
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  if (acc == 0xFFFFFFFFu) *sink = acc;
+}
+// nwg: low 16 bits = workgroups; bit 16 = no LDS allocation (co-resident with anything), bit 17 = no clock polling
+int fact_debug_cu_hog(int nwg, int micros, void* stream) {
+  static bool once = false;
+  if (!once) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(cu_hog_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               96 * 1024));
+    once = true;
+  }
+  static unsigned* sink = nullptr;
+  if (!sink) HIPCHK(hipMalloc((void**)&sink, 4));
+  const int mode = nwg >> 16, n = nwg & 0xFFFF;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(cu_hog_kernel, dim3(n), dim3(256), (mode & 1) ? 1024 : 96 * 1024, (hipStream_t)stream,
+                     (long long)micros * 100, sink, mode);  // wall_clock64() ticks at 100 MHz
+  return 0;
+}
 int fact_debug_attn_timestamps(void* buf) {
   attn_set_ts((unsigned long long*)buf);
   return 0;

@@ -33,6 +33,13 @@ def load(d, agg, calls):
 
 
 def main():
+    argv = list(sys.argv)
+    traffic_json = None
+    if "--traffic-json" in argv:  # also write the dominant wgrad kernel's measured HBM bytes per launch (bench.py reads it)
+        i = argv.index("--traffic-json")
+        traffic_json = argv[i + 1]
+        del argv[i:i + 2]
+    sys.argv = argv
     out = sys.argv[1]
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     calls = collections.defaultdict(int)
@@ -72,6 +79,25 @@ def main():
     text = "\n".join(lines)
     print(text)
     open(out, "a").write(text + "\n")
+    if traffic_json:
+        import json
+        import os
+        tn = [r for r in rows if "big_tn_kernel" in r["name"] and r["rd_mb"] is not None and r["wr_mb"] is not None]
+        if tn:
+            r = tn[0]
+            # a cross-modal layer's eight bf16 operand matrices read once (144.6 MB at 5760 tokens) + its four fp32 weight
+            # gradients written once (29.9 MB; grad_overwrite: plain stores, no read-modify-write), two launches per layer
+            algo = (144.6e6 + 29.9e6) / 2
+            json.dump({"class": "wgrad_group", "kernel": short(r["name"]),
+                       "read_MB_per_launch": round(r["rd_mb"], 1), "write_MB_per_launch": round(r["wr_mb"], 1),
+                       "traffic_bytes": int((r["rd_mb"] + r["wr_mb"]) * 1e6), "algorithmic_bytes_per_launch": int(algo),
+                       "launches_averaged": r["calls"],
+                       "source": "%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py, same run "
+                                 "as that table; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 wide-read correction; mean over "
+                                 "every launch of the kernel, encoder and supervised-rows layers included)" % os.path.basename(out),
+                       "note": "algorithmic = half of a cross-modal layer's eight bf16 operand matrices read once (144.6 MB at "
+                               "5760 tokens) + its four fp32 weight gradients written once (29.9 MB, grad_overwrite)"},
+                      open(traffic_json, "w"), indent=1)
 
 
 if __name__ == "__main__":
