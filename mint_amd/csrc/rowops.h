@@ -49,6 +49,7 @@ struct ColTask {
   float* dbias;
   int C;
   int cg_begin;  // filled by the launcher
+  int cgw;       // filled by the launcher: columns per column group (<= 256, multiple of 4): C = 800 -> 4 groups of 200
 };
 struct ColTasks {
   ColTask t[COL_TASKS_MAX];

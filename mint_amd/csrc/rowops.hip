@@ -326,11 +326,11 @@ __global__ __launch_bounds__(256) void col_tasks_kernel(const ColTasks ts) {
   for (int i = 1; i < COL_TASKS_MAX; ++i)
     if (ti == i) t = ts.t[i];
   const int cg = blockIdx.x - t.cg_begin;
-  const int c0 = cg * 256 + lane * 4;
+  const int c0 = cg * t.cgw + lane * 4;
   const int r_beg = blockIdx.y * ts.rpb, r_end = min(ts.M, r_beg + ts.rpb);
   const bool ln = t.x != nullptr;
   float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f}, ar[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c0 < t.C) {
+  if (lane * 4 < t.cgw && c0 < t.C) {
     constexpr int U = 8;
     for (int r0 = r_beg + wave; r0 < r_end; r0 += 4 * U) {
       bf16x4 dv[U], yb[U];
@@ -369,8 +369,8 @@ __global__ __launch_bounds__(256) void col_tasks_kernel(const ColTasks ts) {
     red[2][wave][lane * 4 + j] = ar[j];
   }
   __syncthreads();
-  const int c = cg * 256 + threadIdx.x;
-  if (c < t.C) {
+  const int c = cg * t.cgw + threadIdx.x;
+  if ((int)threadIdx.x < t.cgw && c < t.C) {
     const int k = threadIdx.x;
     if (ln) {
       atomicAdd(t.dgamma + c, (red[0][0][k] + red[0][1][k]) + (red[0][2][k] + red[0][3][k]));
@@ -1016,7 +1016,10 @@ int launch_col_tasks(ColTasks ts, hipStream_t s) {
     ColTask& t = ts.t[i];
     if ((t.C & 3) || (t.dy && (t.ldy < t.C || (t.ldy & 3))) || (t.x && (t.ld16 < t.C || (t.ld16 & 3)))) return -1;
     t.cg_begin = groups;
-    groups += (t.C + 255) / 256;
+    const int ng = (t.C + 255) / 256;
+    static const bool even = !(getenv("FACT_COL_EVEN") && atoi(getenv("FACT_COL_EVEN")) == 0);  // A/B knob
+    t.cgw = even ? ((((t.C + ng - 1) / ng) + 3) & ~3) : 256;  // even column groups: 800 -> 4 x 200 (not 3 x 256 + 32: an eighth-filled group)
+    groups += ng;
   }
   ts.rpb = 128;
   hipLaunchKernelGGL(col_tasks_kernel, dim3(groups, (ts.M + ts.rpb - 1) / ts.rpb), dim3(256), 0, s, ts);
