@@ -1570,6 +1570,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     adam_set_variant(value);
     return 0;
   }
+  if (!strcmp(key, "k64")) {  // process-wide: 256x160 NT GEMMs on 64-deep ring slots
+    gemm_set_k64(value);
+    return 0;
+  }
   if (!strcmp(key, "grad_overwrite")) {
     h->grad_overwrite = value;
     return 0;

@@ -874,6 +874,7 @@ int g_nt_band = 8;  // tile band height of the 128x128 NT kernel (bench knob; me
 // 10 / 11 / 12 = big-tile family of gemm_big.hip at 288x256 / 256x256 / 256x160 (bench/test knob)
 int g_nt_variant = 0;
 int g_big_impl = 1;  // auto mode: 1 = gemm_big.hip family, 0 = round-1 big kernel (A/B knob)
+int g_k64 = 3;  // auto mode: 64-deep ring slots (bit 0: the 256x160 tile, bit 1: 288x256 / 256x256); 0 = round-2 32-deep slots
 int g_splitk_max = 4;  // in-kernel split-K of the 256x160 tile when the caller hands in a workspace (1 = off)
 
 template <int EPI>
@@ -907,6 +908,8 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
     int cfg = -1, old_mr = 0;
     if (variant >= 10 && variant <= 12) cfg = variant - 10;
     else if (variant == 14) cfg = BIG_256x128;
+    else if (variant == 17)  // 64-deep slots need whole lines in memory: row pitch >= K rounded up to 64
+      cfg = (p.lda >= ((p.K + 63) & ~63) && p.ldb >= ((p.K + 63) & ~63)) ? BIG_256x160_K64 : BIG_256x160;
     else if (variant == 6) old_mr = 9;
     else if (variant == 7) old_mr = 8;
     else if (variant == 0) {
@@ -933,7 +936,15 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
         cfg = BIG_256x128;
       }
     }
-    if (cfg == BIG_256x160 && ws) {
+    const bool k64_ok = p.lda >= ((p.K + 63) & ~63) && p.ldb >= ((p.K + 63) & ~63);
+    if (variant == 18) cfg = k64_ok ? BIG_288x256_K64 : BIG_288x256;
+    if (variant == 19) cfg = k64_ok ? BIG_256x256_K64 : BIG_256x256;
+    if (g_k64 && variant == 0 && k64_ok) {
+      if (cfg == BIG_256x160) cfg = BIG_256x160_K64;
+      else if ((g_k64 & 2) && cfg == BIG_288x256) cfg = BIG_288x256_K64;
+      else if ((g_k64 & 2) && cfg == BIG_256x256) cfg = BIG_256x256_K64;
+    }
+    if ((cfg == BIG_256x160 || cfg == BIG_256x160_K64) && ws) {
       // N = 800 outputs give only 5 column tiles: M = 5760 -> 115 tiles on 256 CUs.  With a workspace each
       // tile is cut along K into 2-4 slices (<= 256 workgroups) that finish in-kernel.
       const int t160 = ((p.N + 159) / 160) * ((p.M + 255) / 256);
@@ -1005,6 +1016,7 @@ int check_common(const GemmParams& p, int epi) {
 
 void gemm_set_nt_variant(int v) { g_nt_variant = v; }
 void gemm_set_big_impl(int v) { g_big_impl = v; }
+void gemm_set_k64(int v) { g_k64 = v; }
 void gemm_set_splitk_max(int v) { g_splitk_max = v < 1 ? 1 : (v > 4 ? 4 : v); }
 void gemm_set_nt_band(int band) { g_nt_band = band; }
 

@@ -53,13 +53,20 @@ DEVINL bf16x4 tr_read(unsigned addr) {
   return r;
 }
 
-template <int WGM_, int MR_, int WGN_, int NR_, int NSTAGE_ = 4, int WGS_PER_CU_ = 1>
+template <int WGM_, int MR_, int WGN_, int NR_, int NSTAGE_ = 4, int WGS_PER_CU_ = 1, int KS_ = 32>
 struct BigCfg {
   static constexpr int WGM = WGM_, MR = MR_, WGN = WGN_, NR = NR_;
   static constexpr int BM = WGM * MR * 16, BN = WGN * NR * 16;
   static constexpr int NSTAGE = NSTAGE_, DIST = NSTAGE - 1;
   static constexpr int WGS_PER_CU = WGS_PER_CU_;  // co-resident workgroups the register / LDS budget is sized for
-  static constexpr int A_PIECES = BM / 16, B_PIECES = BN / 16;  // 1 KiB DMA pieces per 32-deep stage
+  // KS = depth of a ring slot along K.  32 (rounds 1-2): a 1 KiB DMA piece is 16 rows x 64 B - HALF a 128-byte line per
+  // row, so every operand line is requested twice, one K step apart (round-3 PMC: 3.61 M L2 read requests for the
+  // FFN1-shaped GEMM against 1.63 M lines of operand bytes; the 64-deep 128x128 kernel: 3.53 M for 3.46 M lines).
+  // 64 (big_mainloop64, NT only): a piece is 8 rows x 128 B = whole lines; a slot feeds two 32-deep multiply steps.
+  static constexpr int KS = KS_;
+  static_assert(KS == 32 || KS == 64, "slot depth");
+  static constexpr int PROWS = (KS == 64) ? 8 : 16;  // rows per DMA piece
+  static constexpr int A_PIECES = BM / PROWS, B_PIECES = BN / PROWS;  // 1 KiB DMA pieces per stage
   static constexpr int A_BYTES = A_PIECES * 1024;
   static constexpr int NPIECE = A_PIECES + B_PIECES;
   static constexpr int STAGE_BYTES = NPIECE * 1024;
@@ -67,7 +74,7 @@ struct BigCfg {
   static constexpr int NW = WGM * WGN;  // 8 waves: two groups half a K step apart
   static constexpr int LPS_LO = NPIECE / NW, EXTRA = NPIECE % NW;  // waves < EXTRA issue one more piece
   static_assert(NW == 8, "8 waves");
-  static_assert(NSTAGE >= 3 && NSTAGE <= 6, "ring depth");
+  static_assert((NSTAGE >= 3 || KS_ == 64) && NSTAGE >= 2 && NSTAGE <= 6, "ring depth");
   static_assert(LDS_BYTES * WGS_PER_CU <= 160 * 1024, "LDS");
 };
 
@@ -533,6 +540,136 @@ DEVINL void tn_mainloop_pf(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
   __builtin_amdgcn_s_barrier();
 }
 
+// -------------------------------------------------------------------------------------------------
+// NT main loop on 64-DEEP ring slots (round 3).  Same two staggered wave groups and the same 32-deep multiply steps as
+// big_mainloop, but a ring slot now holds 64 k of every row as ONE 128-byte line (image: 16-byte chunk c of row r at
+// position c ^ (r & 7), the layout of the 128x128 kernel - conflict-free ds_read_b128), DMA pieces are 8 rows x 128 B, and
+// a slot feeds two multiply steps ks = 0 / 1 (chunks 4 ks .. 4 ks + 3).  Half-step h = 2 t + ks of stage t:
+//     group 0: read in phase 2h, multiply in phase 2h + 1;   group 1: one phase later.
+// DMA: the pieces of stage t + 2 go into the slot stage t - 1 used (NSTAGE = 3) and are issued from the read phases of
+// stage t, a wave's first half of them in its ks = 0 read phase and the rest in its ks = 1 read phase.
+//   landing: stage t + 1 was issued during stage t - 1; every wave retires its own pieces of it (counted vmcnt: only the
+//            pieces of stage t + 2 may stay in flight) at the end of its ks = 1 read phase of stage t, i.e. before the
+//            barrier that ends phase 4t + 2 (group 0) / 4t + 3 (group 1); the first read of stage t + 1 is phase 4t + 4.
+//   re-use:  the last reads of stage t - 1 are group 1's ks = 1 reads in phase 4t - 1, retired (lgkmcnt) before the
+//            barrier that ends it; the earliest write into that slot is issued in phase 4t.
+// Stages past the end of K are still issued (clamped source) so every wait is a constant count.  nk32 = number of
+// 32-deep steps (the last stage may hold one step only).
+// -------------------------------------------------------------------------------------------------
+template <class C, bool SWAP>
+DEVINL void big_mainloop64(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1], const unsigned (&sadv)[C::LPS_LO + 1],
+                           const unsigned (&voff)[C::LPS_LO + 1], const int (&dst)[C::LPS_LO + 1], int nk32, int wave,
+                           int wm, int wn, int lane, f32x4 (&acc)[C::MR][C::NR]) {
+  constexpr int MR = C::MR, NR = C::NR, NST = C::NSTAGE, STAGE = C::STAGE_BYTES, D = NST - 1;
+  constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
+  static_assert(C::KS == 64 && (NST == 2 || NST == 3), "64-deep slots on a 2- or 3-slot ring");
+  // NST = 3: the pieces of stage t + 2 are issued from the read phases of stage t, half in ks = 0 and half in ks = 1.
+  // NST = 2 (the 288x256 / 256x256 tiles: 68 / 64 KiB per slot): stage t + 1 goes into the slot stage t - 1 used and is
+  // issued entirely from the ks = 0 read phases of stage t; its pieces must have landed two phases later.
+  constexpr int H0 = (D == 2) ? LPS_LO / 2 : LPS_LO;  // pieces [0, H0) go out in the ks = 0 read phase
+  const int grp = wave >> 2;
+  const bool extra = EXTRA && wave < EXTRA;
+  const int nst = (nk32 + 1) >> 1;  // stages
+
+  auto issue = [&](auto slot_c, auto part_c, bool more) {
+    constexpr int SLOT = decltype(slot_c)::value, PART = decltype(part_c)::value;
+    unsigned char* base = smem + SLOT * STAGE;
+    constexpr bool TAIL_HERE = (D == 2) ? (PART == 1) : (PART == 0);  // which part carries the extra piece
+    constexpr int LO = (PART == 0) ? 0 : H0, HI = (PART == 0) ? H0 : LPS_LO;
+#pragma unroll
+    for (int i = LO; i < HI; ++i) {
+      glds16(reinterpret_cast<const bf16_t*>(sptr[i] + voff[i]), base + dst[i]);
+      sptr[i] += more ? sadv[i] : 0u;
+    }
+    if constexpr (TAIL_HERE) {
+      if (extra) glds16(reinterpret_cast<const bf16_t*>(sptr[LPS_LO] + voff[LPS_LO]), base + dst[LPS_LO]);
+      sptr[LPS_LO] += more ? sadv[LPS_LO] : 0u;
+    }
+  };
+  auto wait_landed = [&]() {  // at most D - 1 later stages of this wave stay in flight
+    if constexpr (D == 2) {
+      if (extra) wait_vmcnt<LPS_LO + 1>();
+      else wait_vmcnt<LPS_LO>();
+    } else {
+      wait_vmcnt<0>();
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses: row r = lane & 15 of a 16-row tile (2 KiB), chunk 4 ks + (lane >> 4)
+  const int r = lane & 15, cq = lane >> 4;
+  unsigned lp[2];
+  lp[0] = (unsigned)(r * 128 + (((0 + cq) ^ (r & 7)) << 4));
+  lp[1] = (unsigned)(r * 128 + (((4 + cq) ^ (r & 7)) << 4));
+  const unsigned a_base = (unsigned)(wm * MR * 2048), b_base = (unsigned)(C::A_BYTES + wn * NR * 2048);
+
+  issue(SlotC<0>{}, SlotC<0>{}, 1 < nst);
+  issue(SlotC<0>{}, SlotC<1>{}, 1 < nst);
+  if constexpr (D == 2) {
+    issue(SlotC<1>{}, SlotC<0>{}, 2 < nst);
+    issue(SlotC<1>{}, SlotC<1>{}, 2 < nst);
+  }
+  wait_landed();
+  __builtin_amdgcn_s_barrier();  // stage 0 landed
+
+  bf16x8 af[MR], bfr[NR];
+  auto body = [&](auto slot_c, auto ks_c, int t) {
+    constexpr int SLOT = decltype(slot_c)::value, KSI = decltype(ks_c)::value;
+    constexpr int NEXT = (SLOT + D) % NST;  // slot of stage t + D (= the slot stage t - 1 used)
+    const unsigned char* st = smem + SLOT * STAGE;
+#pragma unroll
+    for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 2048 + lp[KSI]);
+#pragma unroll
+    for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 2048 + lp[KSI]);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (D == 2) {
+      issue(SlotC<NEXT>{}, SlotC<KSI>{}, t + D + 1 < nst);
+    } else if constexpr (KSI == 0) {
+      issue(SlotC<NEXT>{}, SlotC<0>{}, t + D + 1 < nst);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (KSI == 1) wait_landed();  // this wave's pieces of stage t + 1 have landed
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+        acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  // ks = 1 of the last stage when nk32 is odd (K = 800, 2400 ...): that half of the lines is pitch padding and must not be
+  // multiplied - the wave only keeps the barrier / DMA / wait pattern of the half-step.
+  auto body_tail = [&](auto slot_c, int t) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr int NEXT = (SLOT + D) % NST;
+    if constexpr (D == 2) issue(SlotC<NEXT>{}, SlotC<1>{}, false);
+    wait_landed();
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+  };
+  if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one phase behind group 0
+#define BIG64_STAGE(SL, T)                                                        \
+    if ((T) < nst) {                                                              \
+      body(SlotC<SL>{}, SlotC<0>{}, (T));                                         \
+      if (2 * (T) + 1 < nk32) body(SlotC<SL>{}, SlotC<1>{}, (T));                 \
+      else body_tail(SlotC<SL>{}, (T));                                           \
+    }
+  for (int t = 0; t < nst; t += NST) {
+    BIG64_STAGE(0, t)
+    BIG64_STAGE(1, t + 1)
+    if constexpr (NST == 3) { BIG64_STAGE(2, t + 2) }
+  }
+#undef BIG64_STAGE
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  wait_vmcnt<0>();  // the run-ahead stages past the end of K
+  __builtin_amdgcn_s_barrier();
+}
+
 // XCD-aware re-deal of the 1-D grid: block b runs on XCD b % 8 (observed); each XCD gets a contiguous
 // range of logical ids so neighbouring tiles (shared operand panels) hit one private L2.  Bijective.
 DEVINL int xcd_logical_id() {
@@ -581,33 +718,39 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     m0 = (b * band + w % hb) * BM;
     n0 = (w / hb) * BN;
   }
-  const int nk_all = p.K / 32, nk_per = (nk_all + p.splitk - 1) / p.splitk;
+  const int nk_all = p.K / 32;
+  int nk_per = (nk_all + p.splitk - 1) / p.splitk;
+  if constexpr (C::KS == 64) nk_per = (nk_per + 1) & ~1;  // slices start on 64-deep stage boundaries
   const int k_beg = z * nk_per, nk = min(nk_per, nk_all - k_beg);  // host: every slice has >= 1 stage
 
   const char* sptr[C::LPS_LO + 1];
   unsigned sadv[C::LPS_LO + 1], voff[C::LPS_LO + 1];
   int dst[C::LPS_LO + 1];
   {
-    const int lrow = lane >> 2;                     // row inside the 16-row piece
-    const int lchunk = (lane & 3) ^ ring_g(lrow);   // logical 16-byte chunk this lane fetches
+    // 32-deep slots: a piece is 16 rows x 64 B (lane -> row lane >> 2, chunk (lane & 3) ^ ring_g);
+    // 64-deep slots: 8 rows x 128 B (lane -> row lane >> 3, chunk (lane & 7) ^ row)
+    constexpr int PR = C::PROWS;
+    const int lrow = (C::KS == 64) ? (lane >> 3) : (lane >> 2);
+    const int lchunk = (C::KS == 64) ? ((lane & 7) ^ lrow) : ((lane & 3) ^ ring_g(lrow));
 #pragma unroll
     for (int i = 0; i < C::LPS_LO + 1; ++i) {
       const int q = (i < C::LPS_LO) ? wave * C::LPS_LO + i : C::NW * C::LPS_LO + wave;  // extras: pieces NW*LPS_LO..
       const int qq = min(q, C::NPIECE - 1);
       if (qq < C::A_PIECES) {  // wave-uniform
         sptr[i] = reinterpret_cast<const char*>(p.A) + (size_t)k_beg * 64;
-        voff[i] = ((unsigned)min(m0 + qq * 16 + lrow, p.M - 1) * (unsigned)p.lda + lchunk * 8) * 2u;
+        voff[i] = ((unsigned)min(m0 + qq * PR + lrow, p.M - 1) * (unsigned)p.lda + lchunk * 8) * 2u;
         dst[i] = qq * 1024;
       } else {
         sptr[i] = reinterpret_cast<const char*>(p.B) + (size_t)k_beg * 64;
-        voff[i] = ((unsigned)min(n0 + (qq - C::A_PIECES) * 16 + lrow, p.N - 1) * (unsigned)p.ldb + lchunk * 8) * 2u;
+        voff[i] = ((unsigned)min(n0 + (qq - C::A_PIECES) * PR + lrow, p.N - 1) * (unsigned)p.ldb + lchunk * 8) * 2u;
         dst[i] = C::A_BYTES + (qq - C::A_PIECES) * 1024;
       }
-      sadv[i] = 64;  // 32 bf16 along K
+      sadv[i] = (C::KS == 64) ? 128 : 64;  // bytes along K per stage
     }
   }
   f32x4 acc[MR][NR];
-  big_mainloop<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+  if constexpr (C::KS == 64) big_mainloop64<C, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+  else big_mainloop<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
 
   if (p.splitk > 1) {
     // In-launch split-K finish (cdna_hip_programming.md 5 "in-launch split-K reduction", write-through form):
@@ -1027,6 +1170,10 @@ int launch_big_nt_cfg(const GemmParams& p, hipStream_t s) {
     if (!p.sk_slab || !p.sk_cnt || tiles > kSplitKCounters ||
         (size_t)tiles * p.splitk * C::BM * C::BN * 4 > kSplitKSlabBytes || p.K / 32 / p.splitk < 1)
       return -9;
+    if (C::KS == 64) {  // slices are rounded up to whole 64-deep stages: the last one must not be empty
+      const int nk_all = p.K / 32, per = (((nk_all + p.splitk - 1) / p.splitk) + 1) & ~1;
+      if ((p.splitk - 1) * per >= nk_all) return -9;
+    }
   }
   hipLaunchKernelGGL((big_nt_kernel<C, EPI>), dim3(tiles * p.splitk), dim3(C::NW * 64), C::LDS_BYTES, s, p);
   return 0;
@@ -1040,6 +1187,10 @@ using Cfg160x256r6 = BigCfg<2, 5, 4, 4, 6>;  // 6-slot LDS-DMA ring (160 KiB) fo
 // 2 workgroups per CU (3-deep ring, 72 KiB; 64x64 wave tile -> <= 128 VGPRs): the epilogue of one workgroup (bias /
 // GELU math, staging, 35-70 MB of stores for the K = 800 GEMMs) runs under the main loop of the other
 using Cfg256x128 = BigCfg<4, 4, 2, 4, 3, 2>;
+// 256x160 on 64-deep ring slots (3 x 52 KiB): whole 128-byte lines per DMA piece (big_mainloop64)
+using Cfg256x160k64 = BigCfg<4, 4, 2, 5, 3, 1, 64>;
+using Cfg288x256k64 = BigCfg<2, 9, 4, 4, 2, 1, 64>;  // 2 x 68 KiB
+using Cfg256x256k64 = BigCfg<2, 8, 4, 4, 2, 1, 64>;  // 2 x 64 KiB
 
 template <int EPI>
 int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
@@ -1048,6 +1199,9 @@ int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
     case BIG_256x256: return launch_big_nt_cfg<Cfg256x256, EPI>(p, s);
     case BIG_256x160: return launch_big_nt_cfg<Cfg256x160, EPI>(p, s);
     case BIG_256x128: return launch_big_nt_cfg<Cfg256x128, EPI>(p, s);
+    case BIG_256x160_K64: return launch_big_nt_cfg<Cfg256x160k64, EPI>(p, s);
+    case BIG_288x256_K64: return launch_big_nt_cfg<Cfg288x256k64, EPI>(p, s);
+    case BIG_256x256_K64: return launch_big_nt_cfg<Cfg256x256k64, EPI>(p, s);
   }
   return -7;
 }
@@ -1063,6 +1217,9 @@ int big_tile_dims(int cfg, int* bm, int* bn) {
     case BIG_256x160: *bm = 256; *bn = 160; return 0;
     case BIG_160x256: *bm = 160; *bn = 256; return 0;
     case BIG_256x128: *bm = 256; *bn = 128; return 0;
+    case BIG_256x160_K64: *bm = 256; *bn = 160; return 0;
+    case BIG_288x256_K64: *bm = 288; *bn = 256; return 0;
+    case BIG_256x256_K64: *bm = 256; *bn = 256; return 0;
   }
   return -1;
 }
@@ -1070,6 +1227,7 @@ int big_tile_dims(int cfg, int* bm, int* bn) {
 int launch_big_nt(int cfg, int epi, const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
   if (p.K % 32 || p.K < 32 || p.splitk < 1 || p.splitk > 4) return -6;
+  if (cfg >= BIG_256x160_K64 && (p.lda < ((p.K + 63) & ~63) || p.ldb < ((p.K + 63) & ~63) || (p.lda & 7) || (p.ldb & 7))) return -6;
   if ((size_t)p.M * p.lda >= (1ull << 31) || (size_t)p.N * p.ldb >= (1ull << 31)) return -6;  // 32-bit lane offsets
   if (epi == EPI_HEADS) {
     if (p.M >= 65536 || p.N >= 65536) return -8;

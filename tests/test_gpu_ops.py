@@ -104,8 +104,9 @@ def gemm_path(request):
     L.lib().fact_debug_force_generic_gemm(0)
 
 
-@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14],
-                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160", "big256x128x2"])
+@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14, 17, 18, 19],
+                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160", "big256x128x2",
+                     "big256x160k64", "big288x256k64", "big256x256k64"])
 def nt_variant(request):
     """NT kernel choice: the engine's automatic pick, the 128x128 kernel, the round-1 big-tile kernels and
     every tile config of the big-tile family (gemm_big.hip), forced regardless of the tile-count heuristic."""
@@ -175,6 +176,38 @@ def test_gemm_nt_splitk_in_kernel(M, N, K):
     finally:
         lib.fact_debug_gemm_splitk_max(4)
     _close(o1, o2, 1e-5, 1e-4, "split vs unsplit")
+
+
+@pytest.mark.parametrize("M,N,K", [(5760, 800, 3072), (5760, 800, 2400), (700, 800, 800), (300, 500, 96), (256, 160, 32),
+                                   (257, 161, 64), (1920, 800, 3072), (64, 72, 160)])
+@pytest.mark.parametrize("variant", [17, 18, 19], ids=["256x160", "288x256", "256x256"])
+def test_gemm_nt_k64_slots(M, N, K, variant):
+    """256x160 tiles on 64-deep ring slots (big_mainloop64: 8-row x 128-byte DMA pieces, two multiply steps per slot):
+    even / odd numbers of 32-deep steps (K = 96, 160, 800, 2400 end in a half-filled stage whose second step must not be
+    multiplied - the pitch padding behind K holds NaN here), ragged M / N, the in-kernel split-K finish on long K, and
+    every fused epilogue the engine runs on this tile."""
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(31)
+    ld = (K + 63) // 64 * 64
+    A = torch.full((M, ld), float("nan"), device=DEV, dtype=torch.bfloat16)
+    B = torch.full((N, ld), float("nan"), device=DEV, dtype=torch.bfloat16)
+    A[:, :K] = _bf(torch.randn(M, K, device=DEV, generator=g))
+    B[:, :K] = _bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
+    bias = torch.randn(N, device=DEV, generator=g)
+    resid = torch.randn(M, N, device=DEV, generator=g)
+    ref = A[:, :K].float() @ B[:, :K].float().t()
+    lib.fact_debug_gemm_nt_variant(variant)
+    try:
+        o = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _gemm_nt(L.EPI_BF16, A, B, M, N, K, o)
+        _close(o, ref, 1e-2, 1e-2 * math.sqrt(K) * 0.1, "k64 bf16")
+        assert _rel_err(o, ref) < 4e-3
+        for it in range(3):   # split-K workspace re-use (K >= 1536 takes the in-kernel finish)
+            o = torch.full((M, N), float("nan"), device=DEV)
+            _gemm_nt(L.EPI_F32_BIAS_RESID, A, B, M, N, K, o, bias=bias, resid=resid)
+            _close(o, ref + bias + resid, 1e-4, 2e-3, "k64 resid it%d" % it)
+    finally:
+        lib.fact_debug_gemm_nt_variant(0)
 
 
 def test_gemm_nt_epilogues(nt_variant):

@@ -47,8 +47,8 @@ def nt_case(M, N, K, epi, variants, label):
     ref = A[:, :K].float() @ B[:, :K].float().t()
     line = "%-14s M%5d N%5d K%5d:" % (label, M, N, K)
     for v in variants:
-        lib.fact_debug_gemm_splitk_max(1 if v == 112 else 4)   # 112 = 256x160 tiles WITHOUT the in-kernel split-K
-        lib.fact_debug_gemm_nt_variant(12 if v == 112 else v)
+        lib.fact_debug_gemm_splitk_max(1 if v in (112, 117) else 4)   # 112 / 117 = 256x160 tiles WITHOUT the in-kernel split-K
+        lib.fact_debug_gemm_nt_variant(12 if v == 112 else 17 if v == 117 else v)
 
         def launch():
             L.check(lib.fact_op_gemm_nt(epi, L.ptr(A), ld, L.ptr(B), ld, M, N, K, L.ptr(o0), o0.stride(0), L.ptr(o1),
@@ -156,6 +156,31 @@ if __name__ == "__main__":
             nt_case(Me, 3072, 800, L.EPI_GELU_BWD, [1, 10, 11, 14], "enc gelu'")
             nt_case(Me, 800, 3072, L.EPI_BF16, [1, 12, 14], "enc dFFN1")
             nt_case(Me, 800, 2400, L.EPI_BF16, [1, 12, 14], "enc dQKV")
+    if what == "k64":  # 256x160 tiles: 32-deep (v12, v112 = without split-K) vs 64-deep ring slots (v17, v117 = without split-K)
+        M = 5760
+        for rep in range(2):
+            nt_case(M, 800, 3072, L.EPI_BF16, [112, 117, 12, 17], "dgrad FFN1")
+            nt_case(M, 800, 3072, L.EPI_F32_BIAS_RESID, [112, 117, 12, 17], "FFN2+resid")
+            nt_case(M, 800, 2400, L.EPI_BF16, [112, 117, 12, 17], "dgrad QKV")
+            nt_case(M, 800, 800, L.EPI_BF16, [112, 117, 14], "N800 K800")
+        for Me in (3840, 1920):
+            nt_case(Me, 800, 3072, L.EPI_BF16, [112, 117, 12, 17], "enc dFFN1")
+        for rep in range(2):
+            nt_case(M, 3072, 800, L.EPI_BF16, [10, 18], "plain 288x256")
+            nt_case(M, 3072, 800, L.EPI_BIAS_GELU, [10, 18], "FFN1+gelu")
+            nt_case(M, 3072, 800, L.EPI_GELU_BWD, [10, 18], "dgrad gelu'")
+            nt_case(M, 2400, 800, L.EPI_BF16, [11, 19, 10, 18], "QKV (plain)")
+            nt_case(M, 3072, 3072, L.EPI_BF16, [10, 18], "long K")
+    if what == "pmcreq":  # L2 request counts of the plain FFN1-shaped GEMM: 128x128 (64-deep stages) vs 288x256 (32-deep stages)
+        globals()["ITERS"] = 2
+        nt_case(5760, 3072, 800, L.EPI_BF16, [1], "plain 128x128")
+        nt_case(5760, 3072, 800, L.EPI_BF16, [10], "plain 288x256")
+    if what == "pmcloop":  # long-K plain GEMMs: the main loop dominates (PMC breakdown of the loop itself)
+        globals()["ITERS"] = 3
+        nt_case(5760, 3072, 3072, L.EPI_BF16, [10], "long K 288x256")
+        nt_case(5632, 3072, 3072, L.EPI_BF16, [11], "long K 256x256")
+        nt_case(5760, 800, 3072, L.EPI_BF16, [112], "long K 256x160")
+        wgrad_layer(5760)
     if what == "pmc":  # few launches of the kernels of interest (for rocprofv3 --pmc passes)
         ITERS = 4
         globals()["ITERS"] = 4
