@@ -171,6 +171,15 @@ if __name__ == "__main__":
             nt_case(M, 3072, 800, L.EPI_GELU_BWD, [10, 18], "dgrad gelu'")
             nt_case(M, 2400, 800, L.EPI_BF16, [11, 19, 10, 18], "QKV (plain)")
             nt_case(M, 3072, 3072, L.EPI_BF16, [10, 18], "long K")
+    if what == "k64small":  # short-K N = 800 GEMMs: 256x128 x 2 per CU (v14) vs 256x160 on 64-deep slots (v117)
+        for rep in range(2):
+            for Me in (5760, 3840, 1920):
+                nt_case(Me, 800, 800, L.EPI_F32_BIAS_RESID, [14, 117, 112], "out-proj+resid")
+                nt_case(Me, 800, 800, L.EPI_BF16, [14, 117, 112], "N800 K800 bf16")
+            nt_case(3840, 2400, 800, L.EPI_BF16, [14, 11, 19], "enc QKV")
+            nt_case(3840, 3072, 800, L.EPI_BIAS_GELU, [14, 11, 19], "enc FFN1")
+            nt_case(1920, 2400, 800, L.EPI_BF16, [14, 11, 19], "enc QKV")
+            nt_case(1920, 3072, 800, L.EPI_BIAS_GELU, [14, 11, 19], "enc FFN1")
     if what == "pmcreq":  # L2 request counts of the plain FFN1-shaped GEMM: 128x128 (64-deep stages) vs 288x256 (32-deep stages)
         globals()["ITERS"] = 2
         nt_case(5760, 3072, 800, L.EPI_BF16, [1], "plain 128x128")

@@ -39,7 +39,7 @@ struct Cfg {
   static_assert(LDS <= 160 * 1024, "LDS");
 };
 
-template <int BM, int MODE = 0>
+template <int BM, int MODE = 0, bool LINE = false>
 __global__ __launch_bounds__(NW * 64) void panel_nt_kernel(const bf16_t* __restrict__ A, int lda, const bf16_t* __restrict__ B,
                                                             int ldb, bf16_t* __restrict__ C, int ldc, int M, int K) {
   using G = Cfg<BM>;
@@ -50,20 +50,26 @@ __global__ __launch_bounds__(NW * 64) void panel_nt_kernel(const bf16_t* __restr
   const int m0 = blockIdx.x * BM;
   const int nk = K / 32;
   // DMA sources: this wave's 5 weight pieces (rows 80w + 16p + lrow) and, for waves < A_PIECES, one activation piece
-  const int lrow = lane >> 2, lchunk = (lane & 3) ^ ring_g(lrow);
+  // LINE: whole-line pieces (8 rows x 128 B, DMA-only modes): the wave's 80 weight rows x 64 k = 10 pieces per 64-deep stage,
+  // issued 5 per 32-deep step (pieces 0-4 on even steps, 5-9 on odd ones): same bytes per step as the half-line form
+  const int lrow = LINE ? (lane >> 3) : (lane >> 2), lchunk = LINE ? ((lane & 7) ^ lrow) : ((lane & 3) ^ ring_g(lrow));
   const char* bsrc[NR];
+  const char* bsrc2[NR];
 #pragma unroll
-  for (int p = 0; p < NR; ++p)
-    bsrc[p] = reinterpret_cast<const char*>(B) + ((size_t)(wave * WCOLS + p * 16 + lrow) * ldb + lchunk * 8) * 2;
+  for (int p = 0; p < NR; ++p) {
+    bsrc2[p] = reinterpret_cast<const char*>(B) + ((size_t)(wave * WCOLS + (p + NR) * 8 + lrow) * ldb + lchunk * 8) * 2;
+    bsrc[p] = reinterpret_cast<const char*>(B) + ((size_t)(wave * WCOLS + p * (LINE ? 8 : 16) + lrow) * ldb + lchunk * 8) * 2 +
+              (MODE == 3 ? (size_t)blockIdx.x * NCOL * ldb * 2 : MODE == 4 ? (size_t)(blockIdx.x >> 3) * NCOL * ldb * 2 : MODE == 5 ? (size_t)(blockIdx.x & 7) * NCOL * ldb * 2 : 0);
+  }
   const bool has_a = wave < G::A_PIECES;
   const char* asrc = reinterpret_cast<const char*>(A) + ((size_t)min(m0 + (has_a ? wave : 0) * 16 + lrow, M - 1) * lda + lchunk * 8) * 2;
   const int a_dst = (has_a ? wave : 0) * 1024, b_dst = G::A_PIECES * 1024 + wave * NR * 1024;
 
   auto issue = [&](int slot, int kt) {
     unsigned char* base = smem + slot * STAGE;
-    const size_t koff = (size_t)min(kt, nk - 1) * 64;  // run-ahead stages past the end re-read the last one
+    const size_t koff = LINE ? (size_t)(min(kt, nk - 1) >> 1) * 128 : (size_t)min(kt, nk - 1) * 64;
 #pragma unroll
-    for (int p = 0; p < NR; ++p) glds16(bsrc[p] + koff, base + b_dst + p * 1024);
+    for (int p = 0; p < NR; ++p) glds16((LINE && (kt & 1) ? bsrc2[p] : bsrc[p]) + koff, base + b_dst + p * 1024);
     if (has_a) glds16(asrc + koff, base + a_dst);
   };
   f32x4 acc[MR][NR];
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(NW * 64) void panel_nt_kernel(const bf16_t* __restr
     constexpr int SLOT = decltype(slot_c)::value;
     // stage kt landed (this wave's pieces): one later stage may stay in flight
     if (has_a) wait_vm<NR + 1>(); else wait_vm<NR>();
-    if (MODE != 2) __builtin_amdgcn_s_barrier();
+    if (MODE < 2) __builtin_amdgcn_s_barrier();
     issue((SLOT + 2) % 3, kt + 2);
     if (MODE != 0) return;
     const unsigned char* st = smem + SLOT * STAGE;
@@ -120,14 +126,14 @@ __global__ __launch_bounds__(NW * 64) void panel_nt_kernel(const bf16_t* __restr
 
 static float bf2f(bf16_t v) { return (float)v; }
 
-template <int BM, int MODE = 0>
+template <int BM, int MODE = 0, bool LINE = false>
 void run(int M, int K, const bf16_t* dA, const bf16_t* dB, bf16_t* dC, const std::vector<bf16_t>& hA, const std::vector<bf16_t>& hB,
          int lda, int ldb) {
   using G = Cfg<BM>;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(panel_nt_kernel<BM, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(panel_nt_kernel<BM, MODE, LINE>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
   const int grid = (M + BM - 1) / BM;
   hipMemset(dC, 0, (size_t)M * 832 * 2);
-  hipLaunchKernelGGL((panel_nt_kernel<BM, MODE>), dim3(grid), dim3(NW * 64), G::LDS, 0, dA, lda, dB, ldb, dC, 832, M, K);
+  hipLaunchKernelGGL((panel_nt_kernel<BM, MODE, LINE>), dim3(grid), dim3(NW * 64), G::LDS, 0, dA, lda, dB, ldb, dC, 832, M, K);
   hipDeviceSynchronize();
   std::vector<bf16_t> hC((size_t)M * 832);
   hipMemcpy(hC.data(), dC, hC.size() * 2, hipMemcpyDeviceToHost);
@@ -141,33 +147,39 @@ void run(int M, int K, const bf16_t* dA, const bf16_t* dB, bf16_t* dC, const std
   }
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((panel_nt_kernel<BM, MODE>), dim3(grid), dim3(NW * 64), G::LDS, 0, dA, lda, dB, ldb, dC, 832, M, K);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((panel_nt_kernel<BM, MODE, LINE>), dim3(grid), dim3(NW * 64), G::LDS, 0, dA, lda, dB, ldb, dC, 832, M, K);
   hipEventRecord(e0);
   const int iters = 20;
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((panel_nt_kernel<BM, MODE>), dim3(grid), dim3(NW * 64), G::LDS, 0, dA, lda, dB, ldb, dC, 832, M, K);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((panel_nt_kernel<BM, MODE, LINE>), dim3(grid), dim3(NW * 64), G::LDS, 0, dA, lda, dB, ldb, dC, 832, M, K);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / iters;
-  printf("mode %d panel BM %2d  M %d K %4d: %3d workgroups  %7.1f us  %5.0f TFLOP/s  per K step %.0f cycles@2.4GHz  max err %.3g (ref max %.3g)\n", MODE, BM, M, K,
+  printf("%s mode %d panel BM %2d  M %d K %4d: %3d workgroups  %7.1f us  %5.0f TFLOP/s  per K step %.0f cycles@2.4GHz  max err %.3g (ref max %.3g)\n", LINE ? "whole-line" : "half-line ", MODE, BM, M, K,
          grid, us, 2.0 * M * NCOL * K / us / 1e6, us * 2400.0 / (K / 32), maxerr, maxref);
 }
 
 int main() {
   const int M = 5760;
-  for (int K : {800, 2400, 3072}) {
+  for (int K : {800, 3072}) {
     const int lda = (K + 63) / 64 * 64, ldb = lda;
     std::vector<bf16_t> hA((size_t)M * lda), hB((size_t)NCOL * ldb);
+    const size_t bcopies = 181;
     srand(1);
     for (auto& v : hA) v = (bf16_t)((rand() % 2001 - 1000) / 1000.0f);
     for (auto& v : hB) v = (bf16_t)((rand() % 2001 - 1000) / 20000.0f);
     bf16_t *dA, *dB, *dC;
-    hipMalloc((void**)&dA, hA.size() * 2); hipMalloc((void**)&dB, hB.size() * 2); hipMalloc((void**)&dC, (size_t)M * 832 * 2);
+    hipMalloc((void**)&dA, hA.size() * 2); hipMalloc((void**)&dB, hB.size() * 2 * bcopies); hipMalloc((void**)&dC, (size_t)M * 832 * 2);
     hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
-    hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+    for (size_t c = 0; c < bcopies; ++c) hipMemcpy((char*)dB + c * hB.size() * 2, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
     run<32>(M, K, dA, dB, dC, hA, hB, lda, ldb);
     run<48>(M, K, dA, dB, dC, hA, hB, lda, ldb);
     run<32, 1>(M, K, dA, dB, dC, hA, hB, lda, ldb);
     run<32, 2>(M, K, dA, dB, dC, hA, hB, lda, ldb);
+    run<32, 2, true>(M, K, dA, dB, dC, hA, hB, lda, ldb);
+    run<32, 5, true>(M, K, dA, dB, dC, hA, hB, lda, ldb);
+    run<32, 3>(M, K, dA, dB, dC, hA, hB, lda, ldb);   // DMA only, every workgroup its own copy of B
+    run<32, 4>(M, K, dA, dB, dC, hA, hB, lda, ldb);   // ... one copy per 8 consecutive workgroups (= one per XCD slot round)
+    run<32, 5>(M, K, dA, dB, dC, hA, hB, lda, ldb);   // ... one copy per XCD (blockIdx & 7)
 
     hipFree(dA); hipFree(dB); hipFree(dC);
   }
