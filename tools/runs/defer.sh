@@ -1,0 +1,15 @@
+#!/bin/bash
+# deferred optimizer step (adam_defer) A/B on one box, with and without a low-priority optimizer stream
+cd "$(dirname "$0")/../.."
+export TMPDIR=/tmp
+cat > /tmp/_abfmt.py <<'PY'
+import sys, json
+d = json.loads(sys.stdin.readline())
+print(d['ms_per_step'], d['final_loss'])
+PY
+for rnd in 1 2; do
+for cfg in "X=0|" "X=0|--opt adam_defer=1" "FACT_PRIO_OPT=1|--opt adam_defer=1" "FACT_PRIO_OPT=-1|--opt adam_defer=1" "FACT_PRIO_OPT=1|"; do
+  e=${cfg%%|*}; o=${cfg#*|}
+  printf "%-50s " "[$e $o]"
+  env $e timeout 200 python bench.py --steps 30 --warmup 5 --no-cpu-baseline $o 2>/dev/null | python /tmp/_abfmt.py
+done; done
