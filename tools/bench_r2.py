@@ -180,6 +180,13 @@ if __name__ == "__main__":
             nt_case(3840, 3072, 800, L.EPI_BIAS_GELU, [14, 11, 19], "enc FFN1")
             nt_case(1920, 2400, 800, L.EPI_BF16, [14, 11, 19], "enc QKV")
             nt_case(1920, 3072, 800, L.EPI_BIAS_GELU, [14, 11, 19], "enc FFN1")
+    if what == "wide160":  # the wide (N = 2400 / 3072) short-K GEMMs on 256x160 tiles (2 rounds of small tiles vs 1 round of big ones)
+        for rep in range(2):
+            for Me in (5760, 3840):
+                nt_case(Me, 3072, 800, L.EPI_BF16, [10, 18, 112, 117], "plain N3072")
+                nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [10, 18, 112, 117], "FFN1+gelu")
+                nt_case(Me, 3072, 800, L.EPI_GELU_BWD, [10, 18, 112, 117], "dgrad gelu'")
+                nt_case(Me, 2400, 800, L.EPI_BF16, [11, 19, 112, 117], "QKV (plain)")
     if what == "pmcreq":  # L2 request counts of the plain FFN1-shaped GEMM: 128x128 (64-deep stages) vs 288x256 (32-deep stages)
         globals()["ITERS"] = 2
         nt_case(5760, 3072, 800, L.EPI_BF16, [1], "plain 128x128")
