@@ -269,6 +269,8 @@ struct FactHandle {
                               // accumulate semantics of fact_forward_backward.
   int skip = 0;               // TIMING-ONLY ablation mask (results are wrong): 1 wgrad 2 col sums 4 attn bwd 8 ln bwd 16 gelu' dgrad
                               // 32 ffn1 dgrad 64 qkv dgrad 128 out-proj dgrad 256 attn fwd 512 ln fwd
+  bool keep_pre = true;       // forward stores the dense_1 pre-activations (backward's GELU' reads them); inference entry
+                              // points clear it for their call: 2 bytes x ff per token and layer less to write
   int adam_hold = 1;          // in-backward optimizer: hold the head + cross buckets until the last is final
   // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
   fact_grad_cb cb = nullptr;
@@ -855,7 +857,7 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
   {
     KScope k(h, KP_FFN1, s, 2.0 * Md * st.ff * d);
     GemmParams g = gp(a.h2, dp, p.w1.t, p.w1.ldt, M, st.ff, d);
-    g.ep.out0 = a.pre; g.ep.ldo0 = fp; g.ep.out1 = a.g; g.ep.ldo1 = fp; g.ep.bias = P(h, p.b1);
+    g.ep.out0 = h->keep_pre ? a.pre : nullptr; g.ep.ldo0 = fp; g.ep.out1 = a.g; g.ep.ldo1 = fp; g.ep.bias = P(h, p.b1);
     with_ws(h, g, s);
     with_skinny_fwd(h, g, s);
     CHK(launch_gemm_nt(EPI_BIAS_GELU, g, s));
@@ -914,7 +916,7 @@ int layer_forward_sr(FactHandle* h, Stack& st, int l, int B, int T, hipStream_t 
     KScope k(h, KP_FFN1, s, 2.0 * Mrd * st.ff * d);
     GemmParams g = gp(r.h2_c, dp, p.w1.t, p.w1.ldt, Mr, st.ff, d);
     with_skinny(h, g);
-    g.ep.out0 = r.pre_c; g.ep.ldo0 = fp; g.ep.out1 = r.g_c; g.ep.ldo1 = fp; g.ep.bias = P(h, p.b1);
+    g.ep.out0 = h->keep_pre ? r.pre_c : nullptr; g.ep.ldo0 = fp; g.ep.out1 = r.g_c; g.ep.ldo1 = fp; g.ep.bias = P(h, p.b1);
     with_ws(h, g, s);
     CHK(launch_gemm_nt(EPI_BIAS_GELU, g, s));
   }
@@ -1648,6 +1650,11 @@ int fact_forward(FactHandle* h, const float* motion, const float* audio, int B, 
   int rc = check_batch(h, B);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  struct InferScope {  // forward only: nobody reads the pre-activations
+    FactHandle* h;
+    explicit InferScope(FactHandle* hh) : h(hh) { h->keep_pre = getenv("FACT_KEEP_PRE") != nullptr; }  // env: A/B knob
+    ~InferScope() { h->keep_pre = true; }
+  } infer_scope(h);
   CHK(model_forward_hidden(h, motion, (size_t)h->motion.n * h->motion.feat, audio,
                            (size_t)h->audio.n * h->audio.feat, B, s));
   return head_forward(h, B, out, s);
@@ -1936,6 +1943,11 @@ int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, i
     explicit SkinnyScope(FactHandle* hh, bool on) : h(hh) { h->skinny_fwd = on; }
     ~SkinnyScope() { h->skinny_fwd = false; }
   } skinny_scope(h, h->sr_rows != 0);
+  struct InferScope {
+    FactHandle* h;
+    explicit InferScope(FactHandle* hh) : h(hh) { h->keep_pre = getenv("FACT_KEEP_PRE") != nullptr; }  // env: A/B knob
+    ~InferScope() { h->keep_pre = true; }
+  } infer_scope(h);
   for (int i = 0; i < nsteps; ++i) {
     // motion window = frames [i, i+n_m) of the extended track; audio window = frames [i, i+n_a)
     CHK(model_forward_hidden(h, h->ar_motion + (size_t)i * F, ext, audio + (size_t)i * au.feat,

@@ -12,7 +12,7 @@ enum EpiKind : int {
   EPI_F32_BIAS = 1,       // out0 f32  = acc + bias[n]
   EPI_F32_BIAS_POS = 2,   // out0 f32  = acc + bias[n] + pos[m % seq][n]
   EPI_F32_BIAS_RESID = 3, // out0 f32  = acc + bias[n] + resid[m][n]
-  EPI_BIAS_GELU = 4,      // out0 bf16 = acc + bias[n] (pre-activation), out1 bf16 = gelu(pre)
+  EPI_BIAS_GELU = 4,      // out0 bf16 = acc + bias[n] (pre-activation; not stored when out0 == nullptr), out1 bf16 = gelu(pre)
   EPI_GELU_BWD = 5,       // out0 bf16 = acc * gelu'(pre[m][n])
   EPI_HEADS = 6,          // scatter to per-head token-major q/k/v style buffers [B*H][n_pad][dhp]
   EPI_ATOMIC_F32 = 7,     // atomicAdd(out0 f32, alpha * acc)   (split-K wgrad)

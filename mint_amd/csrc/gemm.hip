@@ -67,13 +67,13 @@ DEVINL void epilogue_store(const EpiParams& ep, int M, int N, int row, int col0,
       bf16x4 p0 = {(bf16_t)pre[0], (bf16_t)pre[1], (bf16_t)pre[2], (bf16_t)pre[3]};
       bf16x4 p1 = {(bf16_t)gelu_tanh(pre[0]), (bf16_t)gelu_tanh(pre[1]), (bf16_t)gelu_tanh(pre[2]),
                    (bf16_t)gelu_tanh(pre[3])};
-      *reinterpret_cast<bf16x4*>(o0) = p0;
+      if (ep.out0) *reinterpret_cast<bf16x4*>(o0) = p0;
       *reinterpret_cast<bf16x4*>(o1) = p1;
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (col0 + r < N) {
-          o0[r] = (bf16_t)pre[r];
+          if (ep.out0) o0[r] = (bf16_t)pre[r];
           o1[r] = (bf16_t)gelu_tanh(pre[r]);
         }
     }
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const GemmParams p)
           const int off = lr * 128 + ((ch ^ (lr & 7)) << 4);
           const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + off);
           if (row < p.M && col < p.N) {
-            *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v0;
+            if (NOUT == 1 || ep.out0) *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v0;
             if constexpr (NOUT == 2) {
               const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + REG + off);
               *reinterpret_cast<bf16x8*>((bf16_t*)ep.out1 + (size_t)row * ep.ldo1 + col) = v1;

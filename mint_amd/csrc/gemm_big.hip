@@ -888,7 +888,7 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
               bf16_t* hr = (which == 0) ? h0 : (which == 1) ? h1 : h2;
               if (hr) *reinterpret_cast<bf16x8*>(hr + ((size_t)(b * ep.heads + h) * ep.n_pad + t) * ep.dhp + d) = v0;
             } else {
-              *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v0;
+              if (NOUT == 1 || ep.out0) *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v0;
               if constexpr (NOUT == 2) {
                 const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + REG + lr * STR + ch * 16);
                 *reinterpret_cast<bf16x8*>((bf16_t*)ep.out1 + (size_t)row * ep.ldo1 + col) = v1;
@@ -991,7 +991,7 @@ DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f
     for (int r = 0; r < 4; ++r)
       if (col0 + r < N) {
         const float pre = v[r] + ep.bias[col0 + r];
-        ((bf16_t*)ep.out0)[(size_t)row * ep.ldo0 + col0 + r] = (bf16_t)pre;
+        if (ep.out0) ((bf16_t*)ep.out0)[(size_t)row * ep.ldo0 + col0 + r] = (bf16_t)pre;
         ((bf16_t*)ep.out1)[(size_t)row * ep.ldo1 + col0 + r] = (bf16_t)gelu_tanh(pre);
       }
   } else if constexpr (EPI == EPI_GELU_BWD) {
