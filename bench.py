@@ -98,7 +98,7 @@ KERNEL_SYMBOLS = {
     "out_proj_dgrad+heads": "big_nt_kernel<BigCfg<4,4,2,4,3,2>, EPI_HEADS> (256x128 tiles, 2 workgroups per CU)",
     "attention_fwd": "attn_fwd_st_kernel<80> (streaming, 480 workgroups)",
     "attention_bwd": "attn_bwd_dq_res_kernel<80> + attn_bwd_dkdv_res_kernel<80> (LDS-resident, 160 workgroups each)",
-    "ln_fwd": "ln_fwd_kernel", "ln_bwd_dx": "ln_bwd_dx_kernel<4>", "bias/ln_param_grads": "col_tasks_kernel",
+    "ln_fwd": "ln_fwd_kernel<4>", "ln_bwd_dx": "ln_bwd_dx_kernel<4>", "bias/ln_param_grads": "col_tasks_kernel",
     "adam+shadows": "adam_fused2_kernel<64,false>",
 }
 # CUs a launch of the class can hold at fact_v5 / B = 16 (workgroups of the cross-modal launch, capped at 256; big-tile
@@ -297,6 +297,20 @@ def run_ar(args, device):
                   "rms_output": round(float(out.double().pow(2).mean().sqrt()), 5),
                   "reference": "same engine, sr_rows = 0 (all 360 rows through the last layer, single-pass GEMMs)"}
     fwd_flop = 80.97e9 * B  # BASELINE.md section 2, forward FLOPs per sample
+    # kernel classes of the sampler (engine event recorder, outside the timed region): ms per generated frame-step
+    kern = None
+    if args.profile_steps > 0:
+        psteps = min(args.profile_steps, steps)
+        model.kernel_profile(True)
+        model.infer_auto_regressive(inp, steps=psteps)
+        recs = model.kernel_profile()
+        model.kernel_profile(False)
+        kern = [{"name": r["name"], "launches_per_step": round(r["launches"] / psteps, 1),
+                 "avg_launch_us": round(r["total_ms"] * 1e3 / max(r["launches"], 1), 2),
+                 "ms_per_step": round(r["total_ms"] / psteps, 4),
+                 **({"tflops": round(r["flops"] / r["total_ms"] / 1e9, 1)} if r["flops"] > 0 and r["total_ms"] > 0 else
+                    {"GBps": round(r["bytes"] / r["total_ms"] / 1e6, 1)} if r["bytes"] > 0 and r["total_ms"] > 0 else {})}
+                for r in sorted(recs, key=lambda r: -r["total_ms"]) if r["launches"] > 0]
     print(json.dumps({
         "metric": "generated motion frames/sec (auto-regressive inference) fact_v5_deeper_t10_cm12",
         "value": round(B * steps / dt, 1), "unit": "generated frames/sec", "n_gpus": 1, "steps": steps,
@@ -306,7 +320,7 @@ def run_ar(args, device):
                    "per_gpu_batch": B, "audio_frames": 240 + steps - 1},
         "forward_tflops": round(fwd_flop * steps / dt / 1e12, 1),
         "forward_mfma_frac": round(fwd_flop * steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "parity_full_rows": parity}))
+        "parity_full_rows": parity, "kernels": kern}))
 
 
 def run_scaled(args, device):

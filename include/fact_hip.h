@@ -179,7 +179,7 @@ int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* com
  *                        reference's train_fn has no gradient accumulation either, single_task_trainer.py:141-196);
  *                        with 0 gradients accumulate across calls until fact_adam_step zeroes them.
  *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "bwd_splitk", "aux_stream", "adam_hold", "tn_loop",
- *   "attn_variant", "adam_variant", "big_impl", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on 64-deep ring slots; default 3), "lite_stream": scheduling / kernel-selection knobs of the A/B runs
+ *   "attn_variant", "adam_variant", "big_impl", "ln_fuse", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on 64-deep ring slots; default 3), "lite_stream": scheduling / kernel-selection knobs of the A/B runs
  *   documented in DESIGN.md sections 3 and 6; results are unchanged by them.  "skip": timing-only ablation mask
  *   (DESIGN 6), results are WRONG while it is set.
  * Unknown keys return an error. */

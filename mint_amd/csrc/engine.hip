@@ -74,6 +74,7 @@ struct LayerA {
   bf16_t *h1 = nullptr, *a = nullptr, *h2 = nullptr, *pre = nullptr, *g = nullptr;
   bf16_t* row[3] = {nullptr, nullptr, nullptr};
   float* lse2 = nullptr;
+  bool h1_ready = false;  // transient: the previous layer's FFN2 epilogue pass already wrote h1 / mean1 / rstd1 (ln_fuse)
 };
 
 struct Stack {
@@ -269,6 +270,8 @@ struct FactHandle {
                               // accumulate semantics of fact_forward_backward.
   int skip = 0;               // TIMING-ONLY ablation mask (results are wrong): 1 wgrad 2 col sums 4 attn bwd 8 ln bwd 16 gelu' dgrad
                               // 32 ffn1 dgrad 64 qkv dgrad 128 out-proj dgrad 256 attn fwd 512 ln fwd
+  int ln_fuse = 1;            // skinny-M forward GEMMs with a residual add: the LayerNorm that follows runs inside their
+                              // epilogue pass (one launch less per sub-block; batch-1 AR sampler, supervised-rows layer)
   bool keep_pre = true;       // forward stores the dense_1 pre-activations (backward's GELU' reads them); inference entry
                               // points clear it for their call: 2 bytes x ff per token and layer less to write
   int adam_hold = 1;          // in-backward optimizer: hold the head + cross buckets until the last is final
@@ -714,6 +717,16 @@ void with_skinny_fwd(FactHandle* h, GemmParams& g, hipStream_t s) {
   g.skinny_floats = h->skinny_floats;
 }
 
+// Ask the residual GEMM `g` (already carrying its skinny accumulator) to run the LayerNorm that follows in its epilogue
+// pass; false = it does not take the skinny path and the caller launches the LayerNorm itself.
+bool fuse_ln(FactHandle* h, GemmParams& g, const float* gamma, const float* beta, bf16_t* out, int ld, float* mean,
+             float* rstd) {
+  if (!h->ln_fuse || g.N > 1024 || (g.N & 3) || !gemm_nt_takes_skinny(EPI_F32_BIAS_RESID, g)) return false;
+  g.ep.ln_g = gamma; g.ep.ln_b = beta; g.ep.ln_h = out; g.ep.ln_ldh = ld; g.ep.ln_mean = mean; g.ep.ln_rstd = rstd;
+  g.ep.ln_eps = h->cfg.ln_eps;
+  return true;
+}
+
 // dW[Mo][No] += A^T B ; A [K][Mo(lda)], B [K][No(ldb)]
 int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int ldb, int No, int K,
           float* out, int ldo, hipStream_t s, float* slab = nullptr) {
@@ -826,7 +839,10 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
   LayerP& p = st.lp[l];
   LayerA& a = st.la[l];
   const double Md = (double)M, fl_attn = 4.0 * (double)B * st.H * (double)st.n * st.n * st.dh;
-  {
+  bool ln2_fused = false;
+  if (a.h1_ready) {
+    a.h1_ready = false;  // LayerNorm 1 ran inside the previous layer's FFN2 epilogue pass
+  } else {
     KScope k(h, KP_LN_FWD, s, 0, Md * d * 6.0);
     CHK(launch_ln_fwd(a.x_in, P(h, p.ln1_g), P(h, p.ln1_b), a.h1, dp, a.mean1, a.rstd1, M, d, h->cfg.ln_eps, s));
   }
@@ -848,9 +864,10 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
     g.ep.out0 = a.x_mid; g.ep.ldo0 = d; g.ep.bias = P(h, p.bo); g.ep.resid = a.x_in; g.ep.ldr = d;
     with_ws(h, g, s);
     with_skinny_fwd(h, g, s);
+    ln2_fused = fuse_ln(h, g, P(h, p.ln2_g), P(h, p.ln2_b), a.h2, dp, a.mean2, a.rstd2);
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
-  {
+  if (!ln2_fused) {
     KScope k(h, KP_LN_FWD, s, 0, Md * d * 6.0);
     CHK(launch_ln_fwd(a.x_mid, P(h, p.ln2_g), P(h, p.ln2_b), a.h2, dp, a.mean2, a.rstd2, M, d, h->cfg.ln_eps, s));
   }
@@ -868,6 +885,11 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
     g.ep.out0 = a.x_out; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = a.x_mid; g.ep.ldr = d;
     with_ws(h, g, s);
     with_skinny_fwd(h, g, s);
+    if (l + 1 < st.L && st.la[l + 1].x_in == a.x_out) {  // LayerNorm 1 of the next layer of this stack
+      LayerP& pn = st.lp[l + 1];
+      LayerA& an = st.la[l + 1];
+      an.h1_ready = fuse_ln(h, g, P(h, pn.ln1_g), P(h, pn.ln1_b), an.h1, dp, an.mean1, an.rstd1);
+    }
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
   return 0;
@@ -882,7 +904,10 @@ int layer_forward_sr(FactHandle* h, Stack& st, int l, int B, int T, hipStream_t 
   LayerA& a = st.la[l];
   SrBuf& r = h->sr;
   const double Md = (double)M, Mrd = (double)Mr;
-  {
+  bool ln2_fused = false;
+  if (a.h1_ready) {
+    a.h1_ready = false;
+  } else {
     KScope k(h, KP_LN_FWD, s, 0, Md * d * 6.0);
     CHK(launch_ln_fwd(a.x_in, P(h, p.ln1_g), P(h, p.ln1_b), a.h1, dp, a.mean1, a.rstd1, M, d, h->cfg.ln_eps, s));
   }
@@ -906,9 +931,10 @@ int layer_forward_sr(FactHandle* h, Stack& st, int l, int B, int T, hipStream_t 
     with_skinny(h, g);
     g.ep.out0 = r.x_mid_c; g.ep.ldo0 = d; g.ep.bias = P(h, p.bo); g.ep.resid = r.x_in_c; g.ep.ldr = d;
     with_ws(h, g, s);
+    ln2_fused = fuse_ln(h, g, P(h, p.ln2_g), P(h, p.ln2_b), r.h2_c, dp, r.mean2_c, r.rstd2_c);
     CHK(launch_gemm_nt(EPI_F32_BIAS_RESID, g, s));
   }
-  {
+  if (!ln2_fused) {
     KScope k(h, KP_LN_FWD, s, 0, Mrd * d * 6.0);
     CHK(launch_ln_fwd(r.x_mid_c, P(h, p.ln2_g), P(h, p.ln2_b), r.h2_c, dp, r.mean2_c, r.rstd2_c, Mr, d, h->cfg.ln_eps, s));
   }
@@ -1582,6 +1608,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
   }
   if (!strcmp(key, "skip")) {
     h->skip = value;
+    return 0;
+  }
+  if (!strcmp(key, "ln_fuse")) {
+    h->ln_fuse = value;
     return 0;
   }
   if (!strcmp(key, "adam_hold")) {

@@ -39,6 +39,16 @@ struct EpiParams {
   size_t slab_stride;  // EPI_F32_SLAB: floats between consecutive k-split slabs
   int z;               // (device) k-split index of this block, filled in by the kernel
   unsigned mg_hid, mg_dh, mg_ntok;  // EPI_HEADS in the big-tile kernels: 2^32 / d + 1 (filled by the launcher)
+  // Optional LayerNorm of the output row fused into the skinny-M epilogue pass (EPI_F32_BIAS_RESID only, N <= 1024; ask
+  // gemm_nt_takes_skinny first - other paths ignore it): ln_h bf16 [M][ln_ldh] = LN(out0 row) * ln_g + ln_b, and the row
+  // statistics.  The next LayerNorm of the forward then costs no launch of its own.
+  const float* ln_g;
+  const float* ln_b;
+  bf16_t* ln_h;
+  int ln_ldh;
+  float* ln_mean;
+  float* ln_rstd;
+  float ln_eps;
 };
 
 struct GemmParams {
@@ -100,6 +110,8 @@ void gemm_set_tn_cfg(int v);  // 0 = 160x256 tiles (default), 1 = 160x384 tiles
 
 // skinny-M epilogue pass (gemm_big.hip): out = epilogue(acc[M][ldacc]), acc <- 0
 int launch_skinny_epilogue(int epi, float* acc, int ldacc, const GemmParams& p, hipStream_t stream);
+// true when launch_gemm_nt(epi, p, .) will run the skinny-M path (split-K atomics + epilogue pass)
+bool gemm_nt_takes_skinny(int epi, const GemmParams& p);
 
 // Launchers. Return 0 on success, negative on invalid arguments.
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);

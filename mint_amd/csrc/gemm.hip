@@ -930,6 +930,10 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
         else old_mr = (e8 > e9) ? 8 : 9;
       } else if (g_big_impl && n800 && p.K >= 1536 && (t160 >= 100 || (ws && t160 >= 32))) {
         cfg = BIG_256x160;  // long K: the in-kernel split-K (with a workspace) fills the chip
+      } else if (g_big_impl && n800 && t160 > 160 && t160 <= 256) {
+        // short K, but one well-filled round of 256x160 tiles (the AR sampler at 32 sequences: M = 11520 -> 225 tiles):
+        // out-proj + residual 28.0 vs 34.2 us on the 256x128 pairs (tools/bench_r2.py ar32)
+        cfg = BIG_256x160;
       } else if (g_big_impl == 1 && t128 >= 48 && t128 <= 512) {  // g_big_impl == 2: A/B without this config
         // short-K N = 800 GEMMs and the wide GEMMs of a short token count (motion encoder): 256x128 tiles, two
         // workgroups per CU (round-2 bench: N800 K800 20.1 vs 22.4 us, M1920 N3072 20.2 vs 23.1 us)
@@ -1020,19 +1024,28 @@ void gemm_set_k64(int v) { g_k64 = v; }
 void gemm_set_splitk_max(int v) { g_splitk_max = v < 1 ? 1 : (v > 4 ? 4 : v); }
 void gemm_set_nt_band(int band) { g_nt_band = band; }
 
+// K split of the skinny-M path, 0 = the GEMM does not take it
+static int skinny_split(int epi, const GemmParams& p) {
+  if (!(p.skinny_acc && p.M <= 512 && p.splitk == 1 && !p.force_generic && !(p.K & 31) && !(p.K & 7) && g_nt_variant == 0 &&
+        (epi == EPI_BF16 || epi == EPI_F32_BIAS || epi == EPI_F32_BIAS_RESID || epi == EPI_BIAS_GELU ||
+         epi == EPI_GELU_BWD || epi == EPI_HEADS || epi == EPI_F32_BF16)))
+    return 0;
+  const int ldacc = (p.N + 3) & ~3;
+  const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128), ktiles = (p.K + 63) / 64;
+  int sk = 256 / tiles;
+  if (sk > ktiles / 2) sk = ktiles / 2;
+  return (sk >= 2 && (size_t)p.M * ldacc <= p.skinny_floats) ? sk : 0;
+}
+bool gemm_nt_takes_skinny(int epi, const GemmParams& p) { return check_common(p, epi) == 0 && skinny_split(epi, p) > 0; }
+
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t s) {
   int rc = check_common(p, epi);
   if (rc) return rc;
   if (p.K & 7) return -6;
   // Skinny-M path (GemmParams::skinny_acc): few row tiles -> cut K so that ~256 workgroups share the GEMM
-  if (p.skinny_acc && p.M <= 512 && p.splitk == 1 && !p.force_generic && !(p.K & 31) && g_nt_variant == 0 &&
-      (epi == EPI_BF16 || epi == EPI_F32_BIAS || epi == EPI_F32_BIAS_RESID || epi == EPI_BIAS_GELU ||
-       epi == EPI_GELU_BWD || epi == EPI_HEADS || epi == EPI_F32_BF16)) {
+  if (const int sk = skinny_split(epi, p)) {
     const int ldacc = (p.N + 3) & ~3;
-    const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128), ktiles = (p.K + 63) / 64;
-    int sk = 256 / tiles;
-    if (sk > ktiles / 2) sk = ktiles / 2;
-    if (sk >= 2 && (size_t)p.M * ldacc <= p.skinny_floats) {
+    {
       GemmParams q = p;
       q.splitk = sk;
       q.skinny_acc = nullptr;

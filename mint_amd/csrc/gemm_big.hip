@@ -1150,6 +1150,63 @@ __global__ __launch_bounds__(256) void skinny_epilogue_kernel(float* __restrict_
   }
 }
 
+// ... fused with the LayerNorm that follows the residual add (EpiParams::ln_*): one wave per output row,
+//   x = acc + bias + resid (stored fp32, same operation order as the element-wise pass), acc <- 0,
+//   h = (x - mean) * rstd * gamma + beta as bf16 (the arithmetic of rowops.hip ln_fwd_kernel) + the row statistics.
+template <int MAXV>
+__global__ __launch_bounds__(256) void skinny_epilogue_ln_kernel(float* __restrict__ acc, int ldacc, const GemmParams p) {
+  const EpiParams& ep = p.ep;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int nv = p.N >> 2;
+  float4* ar = reinterpret_cast<float4*>(acc + (size_t)row * ldacc);
+  const float4* rr = reinterpret_cast<const float4*>(ep.resid + (size_t)row * ep.ldr);
+  const float4* b4 = reinterpret_cast<const float4*>(ep.bias);
+  float4* xo = reinterpret_cast<float4*>((float*)ep.out0 + (size_t)row * ep.ldo0);
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float4 a = ar[idx], b = b4[idx], r = rr[idx];
+      ar[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[i] = make_float4((a.x + b.x) + r.x, (a.y + b.y) + r.y, (a.z + b.z) + r.z, (a.w + b.w) + r.w);
+      xo[idx] = v[i];
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mu = wave_sum(s) / (float)p.N;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
+      q += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)p.N + ep.ln_eps);
+  if (lane == 0) {
+    ep.ln_mean[row] = mu;
+    ep.ln_rstd[row] = rs;
+  }
+  const float4* g4 = reinterpret_cast<const float4*>(ep.ln_g);
+  const float4* be4 = reinterpret_cast<const float4*>(ep.ln_b);
+  bf16x4* hr = reinterpret_cast<bf16x4*>(ep.ln_h + (size_t)row * ep.ln_ldh);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      const float4 g = g4[idx], b = be4[idx];
+      bf16x4 o = {(bf16_t)((v[i].x - mu) * rs * g.x + b.x), (bf16_t)((v[i].y - mu) * rs * g.y + b.y),
+                  (bf16_t)((v[i].z - mu) * rs * g.z + b.z), (bf16_t)((v[i].w - mu) * rs * g.w + b.w)};
+      hr[idx] = o;
+    }
+  }
+}
+
 template <typename K>
 int allow_lds(K kernel, int bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1249,6 +1306,13 @@ int launch_big_nt(int cfg, int epi, const GemmParams& p_in, hipStream_t s) {
 
 int launch_skinny_epilogue(int epi, float* acc, int ldacc, const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
+  if (p.ep.ln_h) {  // fused LayerNorm of the output rows (gemm.h EpiParams::ln_*)
+    if (epi != EPI_F32_BIAS_RESID || (p.N & 3) || p.N > 1024 || !p.ep.bias || !p.ep.resid || (p.ep.ldo0 & 3) || (p.ep.ldr & 3) ||
+        (p.ep.ln_ldh & 3) || !p.ep.ln_g || !p.ep.ln_b || !p.ep.ln_mean || !p.ep.ln_rstd)
+      return -9;
+    hipLaunchKernelGGL((skinny_epilogue_ln_kernel<4>), dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, acc, ldacc, p);
+    return 0;
+  }
   const int total = p.M * ((p.N + 3) >> 2);
   const dim3 grid((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), block(256);
   switch (epi) {

@@ -187,6 +187,13 @@ if __name__ == "__main__":
                 nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [10, 18, 112, 117], "FFN1+gelu")
                 nt_case(Me, 3072, 800, L.EPI_GELU_BWD, [10, 18, 112, 117], "dgrad gelu'")
                 nt_case(Me, 2400, 800, L.EPI_BF16, [11, 19, 112, 117], "QKV (plain)")
+    if what == "ar32":  # the AR sampler's forward GEMMs at 32 sequences (M = 11520)
+        M = 11520
+        for rep in range(2):
+            nt_case(M, 800, 800, L.EPI_F32_BIAS_RESID, [0, 14, 117, 112, 1], "out-proj+resid")
+            nt_case(M, 800, 3072, L.EPI_F32_BIAS_RESID, [0, 117, 17, 14], "FFN2+resid")
+            nt_case(M, 2400, 800, L.EPI_BF16, [0, 18, 19, 117], "QKV (plain)")
+            nt_case(M, 3072, 800, L.EPI_BIAS_GELU, [0, 18, 19, 117], "FFN1+gelu")
     if what == "pmcreq":  # L2 request counts of the plain FFN1-shaped GEMM: 128x128 (64-deep stages) vs 288x256 (32-deep stages)
         globals()["ITERS"] = 2
         nt_case(5760, 3072, 800, L.EPI_BF16, [1], "plain 128x128")
