@@ -1032,7 +1032,9 @@ static int skinny_split(int epi, const GemmParams& p) {
     return 0;
   const int ldacc = (p.N + 3) & ~3;
   const int tiles = ((p.M + 127) / 128) * ((p.N + 127) / 128), ktiles = (p.K + 63) / 64;
-  int sk = 256 / tiles;
+  // ~136 workgroups: every extra K slice adds a 128x128 tile of fp32 atomics (tools/skinny_bench.py at M = 360: QKV 11.4 us
+  // at 2 slices / 13.2 at 4, FFN1 12.8 at 2 / 14.2 at 3, FFN2 13.0 at 6 / 16.3 at 12)
+  int sk = (136 + tiles / 2) / tiles;
   if (sk > ktiles / 2) sk = ktiles / 2;
   return (sk >= 2 && (size_t)p.M * ldacc <= p.skinny_floats) ? sk : 0;
 }
