@@ -22,7 +22,7 @@ if has pmc; then
   python $R/tools/step_pmc.py $O/step_pmc.txt $dirs --traffic-json $O/roofline_traffic.json | head -16; rm -rf $dirs
 fi
 if has standalone; then
-  (cd $R && { timeout 300 python tools/bench_r2.py nt; TN_LOOPS=0,2 timeout 200 python tools/bench_r2.py tn; timeout 200 python tools/rowops_bench.py; } > $O/standalone.txt 2>&1; grep -v amdgpu.ids $O/standalone.txt | head -40)
+  (cd $R && { timeout 300 python tools/bench_r2.py nt; timeout 200 python tools/bench_r2.py k64; TN_LOOPS=0,2 timeout 200 python tools/bench_r2.py tn; timeout 200 python tools/rowops_bench.py; } > $O/standalone.txt 2>&1; grep -v amdgpu.ids $O/standalone.txt | head -40)
 fi
 if has ar; then (cd $R && timeout 300 python bench.py --mode ar --steps 64 --warmup 4 2> $O/ar.err | tail -1 > $O/ar.json; cut -c1-600 $O/ar.json); fi
 if has scaled; then (cd $R && timeout 600 python bench.py --mode scaled --steps 3 --warmup 1 --parity 2> $O/scaled.err | tail -1 > $O/scaled.json; cut -c1-900 $O/scaled.json; tail -2 $O/scaled.err); fi
