@@ -96,7 +96,7 @@ def main():
                                  "as that table; traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 wide-read correction; mean over "
                                  "every launch of the kernel, encoder and supervised-rows layers included)" % os.path.basename(out),
                        "note": "algorithmic = half of a cross-modal layer's eight bf16 operand matrices read once (144.6 MB at "
-                               "5760 tokens) + its four fp32 weight gradients written once (29.9 MB, grad_overwrite); FETCH_SIZE counts every L2 fill, also those the 256 MB Infinity Cache serves: each of the 8 XCD L2s fills its own copy of the operand panels its ~12 tiles of a launch share (5 + 3 panels of 1.8 / 2.9 MB per K pass for a 5 x 2.4 patch, against 8 panels for the whole launch), so read traffic above the read-once figure is the cost of eight private L2s, not of re-reads within one (L2 hit rate of the kernel 69 %%: a line is used by 2.4-5 workgroups of an XCD)"},
+                               "5760 tokens) + its four fp32 weight gradients written once (29.9 MB, grad_overwrite); FETCH_SIZE counts every L2 fill, also those the 256 MB Infinity Cache serves: each of the 8 XCD L2s fills its own copy of the operand panels its ~12 tiles of a launch share (5 + 3 panels of 1.8 / 2.9 MB per K pass for a 5 x 2.4 patch, against 8 panels for the whole launch), so read traffic above the read-once figure is the cost of eight private L2s, not of re-reads within one (L2 hit rate of the kernel 69 %: a line is used by 2.4-5 workgroups of an XCD)"},
                       open(traffic_json, "w"), indent=1)
 
 
