@@ -258,6 +258,18 @@ def _oracle_step(O, params, m, v, step, cfg, batch):
     return p, m, v
 
 
+def class_table(model, psteps):
+    """Kernel classes recorded by the engine's event recorder since kernel_profile(True), per step."""
+    recs = model.kernel_profile()
+    model.kernel_profile(False)
+    return [{"name": r["name"], "launches_per_step": round(r["launches"] / psteps, 1),
+             "avg_launch_us": round(r["total_ms"] * 1e3 / max(r["launches"], 1), 2),
+             "ms_per_step": round(r["total_ms"] / psteps, 4),
+             **({"tflops": round(r["flops"] / r["total_ms"] / 1e9, 1)} if r["flops"] > 0 and r["total_ms"] > 0 else
+                {"GBps": round(r["bytes"] / r["total_ms"] / 1e6, 1)} if r["bytes"] > 0 and r["total_ms"] > 0 else {})}
+            for r in sorted(recs, key=lambda r: -r["total_ms"]) if r["launches"] > 0]
+
+
 def run_ar(args, device):
     """BASELINE.json configs[3], per-GPU share: 32 sequences, 120-frame seed, `steps` generated frames each
     (full forward per frame: no KV cache is possible, fact_model.py:103-132)."""
@@ -303,14 +315,7 @@ def run_ar(args, device):
         psteps = min(args.profile_steps, steps)
         model.kernel_profile(True)
         model.infer_auto_regressive(inp, steps=psteps)
-        recs = model.kernel_profile()
-        model.kernel_profile(False)
-        kern = [{"name": r["name"], "launches_per_step": round(r["launches"] / psteps, 1),
-                 "avg_launch_us": round(r["total_ms"] * 1e3 / max(r["launches"], 1), 2),
-                 "ms_per_step": round(r["total_ms"] / psteps, 4),
-                 **({"tflops": round(r["flops"] / r["total_ms"] / 1e9, 1)} if r["flops"] > 0 and r["total_ms"] > 0 else
-                    {"GBps": round(r["bytes"] / r["total_ms"] / 1e6, 1)} if r["bytes"] > 0 and r["total_ms"] > 0 else {})}
-                for r in sorted(recs, key=lambda r: -r["total_ms"]) if r["launches"] > 0]
+        kern = class_table(model, psteps)
     print(json.dumps({
         "metric": "generated motion frames/sec (auto-regressive inference) fact_v5_deeper_t10_cm12",
         "value": round(B * steps / dt, 1), "unit": "generated frames/sec", "n_gpus": 1, "steps": steps,
@@ -358,6 +363,13 @@ def run_scaled(args, device):
         loss = tr.train_step(it)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    kern = None
+    if args.profile_steps > 0:
+        psteps = min(args.profile_steps, 2)
+        model.kernel_profile(True)
+        for _ in range(psteps):
+            tr.train_step(it)
+        kern = class_table(model, psteps)
     parity = None
     if args.parity:
         parity = scaled_parity(model, device)
@@ -376,7 +388,7 @@ def run_scaled(args, device):
                    "motion_seq": 480, "audio_seq": 960, "hidden": d, "cross_layers": 24, "params": nparams},
         "step_tflops": round(step_flop / dt / 1e12, 1),
         "step_mfma_frac": round(step_flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(float(loss), 5),
-        "parity_vs_oracle": parity}))
+        "parity_vs_oracle": parity, "kernels": kern}))
 
 
 def scaled_parity(model, device):
