@@ -998,7 +998,7 @@ constexpr float ST_THR = 6.0f;  // lazy running max: P = exp2(t) stays below 2^6
 // "ones" A-fragment adds one 16-row tile to O^T whose row 0 is sum_k P[k][q], accumulated (and rescaled) by the
 // MFMA pipe from the same bf16 P that multiplies V.
 template <int DH>
-__global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, DH > 96 ? 2 : 3) void attn_fwd_st_kernel(const AttnParams p) {
   using G = Geo<DH>;
   using S = SG<DH>;
   constexpr int IMG = S::IMG, STAGE = 2 * IMG, PPW = S::PPW, ND = G::ND;
@@ -1156,7 +1156,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_st_kernel(const AttnParams p)
 
 // ---- dQ ------------------------------------------------------------------------------------------
 template <int DH>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_st_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, DH > 96 ? 2 : 3) void attn_bwd_dq_st_kernel(const AttnParams p) {
   using G = Geo<DH>;
   using S = SG<DH>;
   constexpr int IMG = S::IMG, STAGE = 2 * IMG, PPW = S::PPW, ND = G::ND;
@@ -1296,7 +1296,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_st_kernel(const AttnParams
 // Own rows = 32 keys per wave (K, V fragments and both accumulators in registers); streamed: Q and dO tiles
 // plus the 32 log-sum-exp / rowsum(dO o O) values of the tile's queries (one 256-byte piece, wave 0).
 template <int DH>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_st_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, DH > 96 ? 1 : 2) void attn_bwd_dkdv_st_kernel(const AttnParams p) {
   using G = Geo<DH>;
   using S = SG<DH>;
   constexpr int IMG = S::IMG, STAGE = 2 * IMG + 256, PPW = S::PPW, ND = G::ND;
@@ -1501,7 +1501,8 @@ int allow_lds_bytes(K kernel, bool* done, size_t bytes) {
 
 template <int DH>
 int fwd_t(const AttnParams& p, hipStream_t s) {
-  if constexpr (DH <= 96) if ((g_attn_variant == 2 || g_attn_variant == 3) && !g_attn_force_tiled) {
+  // streaming kernel: the default forward; also whatever the resident kernels cannot hold (head dims above 96, n > 384)
+  if ((g_attn_variant == 2 || g_attn_variant == 3 || !res_lds_bytes<DH>(p.n, 0)) && !g_attn_force_tiled) {
     constexpr size_t lds = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG;
     static bool attr = false;
     if (int rc = allow_lds_bytes(attn_fwd_st_kernel<DH>, &attr, lds)) return rc;
@@ -1522,7 +1523,8 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
 }
 template <int DH>
 int bwd_t(const AttnParams& p, hipStream_t s) {
-  if constexpr (DH <= 96) if ((g_attn_variant == 2 || g_attn_variant == 4) && !g_attn_force_tiled) {
+  if ((g_attn_variant == 2 || g_attn_variant == 4 || !res_lds_bytes<DH>(p.n, 1) || !res_lds_bytes<DH>(p.n, 2)) &&
+      !g_attn_force_tiled) {
     constexpr size_t lds1 = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG, lds2 = (size_t)SG<DH>::NSLOT * (2 * SG<DH>::IMG + 256);
     static bool attr1 = false, attr2 = false;
     if (int rc = allow_lds_bytes(attn_bwd_dq_st_kernel<DH>, &attr1, lds1)) return rc;

@@ -425,7 +425,7 @@ def attn_path(request):
 
 
 @pytest.mark.parametrize("B,H,n,dh", [(2, 4, 32, 32), (1, 2, 96, 64), (2, 10, 360, 80), (2, 10, 120, 80),
-                                      (1, 10, 240, 80), (2, 3, 200, 128), (3, 2, 376, 80), (1, 2, 400, 80)])
+                                      (1, 10, 240, 80), (2, 3, 200, 128), (3, 2, 376, 80), (1, 2, 400, 80), (1, 3, 1440, 128)])
 def test_attention_fwd_bwd(attn_path, B, H, n, dh):
     lib = L.lib()
     hid = H * dh
