@@ -953,6 +953,8 @@ int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
   if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0 || ldh < C || (ldh & 3)) return -1;
   if (C <= 1024)
     hipLaunchKernelGGL((ln_fwd_kernel<4>), dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd, M, C, ldh, eps);
+  else if (C <= 1536)
+    hipLaunchKernelGGL((ln_fwd_kernel<6>), dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd, M, C, ldh, eps);
   else
     hipLaunchKernelGGL((ln_fwd_kernel<LN_MAXV>), dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd, M, C, ldh,
                        eps);
@@ -993,6 +995,9 @@ int launch_ln_bwd_dx(const bf16_t* dh, const float* x, const float* mean, const 
   const int grid = (M + 3) / 4;
   if (C <= 1024)
     hipLaunchKernelGGL((ln_bwd_dx_kernel<4>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
+                       M, C, ld16);
+  else if (C <= 1536)
+    hipLaunchKernelGGL((ln_bwd_dx_kernel<6>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
                        M, C, ld16);
   else
     hipLaunchKernelGGL((ln_bwd_dx_kernel<8>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
