@@ -1009,7 +1009,9 @@ __global__ __launch_bounds__(256, DH > 96 ? 2 : 3) void attn_fwd_st_kernel(const
   const int T = (p.n + 31) >> 5;
   const size_t row_base = (size_t)bh * p.NP * G::DHP;
   const int q0 = blockIdx.x * 128 + wave * 32;
-  const bool active = q0 < p.n;  // wave-uniform; inactive waves still stage and synchronise
+  // wave-uniform; inactive waves still stage and synchronise.  Supervised-rows shortcut (nq): only the first nq queries of
+  // a sequence are wanted - the launcher sizes the grid for them, waves past them only help with the staging
+  const bool active = q0 < ((p.nq > 0 && p.nq < p.n) ? p.nq : p.n);
 
   bf16x8 Qf[2][G::KD];
 #pragma unroll
@@ -1506,7 +1508,12 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG;
     static bool attr = false;
     if (int rc = allow_lds_bytes(attn_fwd_st_kernel<DH>, &attr, lds)) return rc;
-    hipLaunchKernelGGL(attn_fwd_st_kernel<DH>, dim3((p.n + 127) / 128, p.B * p.H), dim3(256), lds, s, p);
+    // supervised-rows shortcut: only where the backward that may follow is nq-aware too (the resident kernels; the streaming
+    // backward reads the log-sum-exp of every row)
+    AttnParams q = p;
+    if (!(res_lds_bytes<DH>(p.n, 1) && res_lds_bytes<DH>(p.n, 2))) q.nq = 0;
+    const int nqv = (q.nq > 0 && q.nq < q.n) ? q.nq : q.n;
+    hipLaunchKernelGGL(attn_fwd_st_kernel<DH>, dim3((nqv + 127) / 128, q.B * q.H), dim3(256), lds, s, q);
     return 0;
   }
   const size_t lds = res_lds_bytes<DH>(p.n, 0);
