@@ -1307,6 +1307,8 @@ int copy2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t widt
 int model_forward_hidden(FactHandle* h, const float* motion, size_t m_stride, const float* audio,
                          size_t a_stride, int B, hipStream_t s, int sr_T = 0) {
   Stack &mo = h->motion, &au = h->audio, &cr = h->cross;
+  for (Stack* st : {&mo, &au, &cr})  // (a forward that failed half-way must not leave a "LayerNorm 1 already done" mark behind)
+    for (LayerA& la : st->la) la.h1_ready = false;
   hipStream_t w = side_of(h, s);
   if (w != s) stream_after(h, s, w);
   CHK(embed_forward(h, au, audio, a_stride, B, w));
