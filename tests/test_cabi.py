@@ -64,3 +64,19 @@ def test_product_path_has_no_cpu_fallback():
     for mod in ("trainer", "model_builder", "configs", "config_util", "learning_schedules", "protos"):
         path = os.path.join(ROOT, "mint_amd", mod + ".py")
         assert "from oracle" not in open(path).read() and "import oracle" not in open(path).read()
+
+
+def test_documented_options_exist_in_the_engine():
+    """Every option key the header documents for fact_set_option is one the engine accepts (and the A/B knobs the
+    engine accepts are documented): the comment block is the only specification of that string-keyed interface."""
+    text = open(HEADER).read()
+    block = text[text.index("/* Engine knobs"):text.index("int fact_set_option")]
+    documented = set(re.findall(r'"([a-z0-9_]+)"', block))
+    engine = open(os.path.join(ROOT, "mint_amd", "csrc", "engine.hip")).read()
+    body = engine[engine.index("int fact_set_option(FactHandle* h, const char* key, int value) {"):]
+    body = body[:body.index("\nint fact_forward(")]
+    accepted = set(re.findall(r'!strcmp\(key, "([a-z0-9_]+)"\)', body))
+    assert documented, "no option names found in the header comment"
+    assert documented <= accepted, "documented but not accepted: %s" % sorted(documented - accepted)
+    undocumented = accepted - documented
+    assert not undocumented, "accepted by fact_set_option but missing from include/fact_hip.h: %s" % sorted(undocumented)
