@@ -1,5 +1,8 @@
 #!/bin/bash
-# deferred optimizer step (adam_defer) A/B on one box, with and without a low-priority optimizer stream
+# deferred optimizer step (adam_defer) A/B on one box, with and without a low-priority optimizer stream.
+# RECORD of a measured-and-dropped experiment: the engine option `adam_defer` (optimizer buckets after backward in
+# forward order, one event each, the next forward waiting layer by layer, a fact_join entry point) was removed again after this
+# run - the script no longer runs against the tree.
 cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 cat > /tmp/_abfmt.py <<'PY'
