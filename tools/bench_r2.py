@@ -194,6 +194,12 @@ if __name__ == "__main__":
             nt_case(M, 800, 3072, L.EPI_F32_BIAS_RESID, [0, 117, 17, 14], "FFN2+resid")
             nt_case(M, 2400, 800, L.EPI_BF16, [0, 18, 19, 117], "QKV (plain)")
             nt_case(M, 3072, 800, L.EPI_BIAS_GELU, [0, 18, 19, 117], "FFN1+gelu")
+    if what == "enc32":  # encoder GEMMs of the AR sampler at 32 sequences (audio stack: M = 7680)
+        for rep in range(2):
+            nt_case(7680, 2400, 800, L.EPI_BF16, [0, 14, 11, 19, 1], "audio QKV")
+            nt_case(7680, 3072, 800, L.EPI_BIAS_GELU, [0, 14, 18, 1], "audio FFN1")
+            nt_case(7680, 800, 3072, L.EPI_F32_BIAS_RESID, [0, 17, 117], "audio FFN2")
+            nt_case(7680, 800, 800, L.EPI_F32_BIAS_RESID, [0, 14, 117], "audio out-proj")
     if what == "pmcreq":  # L2 request counts of the plain FFN1-shaped GEMM: 128x128 (64-deep stages) vs 288x256 (32-deep stages)
         globals()["ITERS"] = 2
         nt_case(5760, 3072, 800, L.EPI_BF16, [1], "plain 128x128")
