@@ -17,7 +17,8 @@ therefore the reference's, not a restatement; only the primitives are ours (docu
 Output: tests/golden/reference_tiny_golden.npz (inputs, checksums of the seeded weights - the tests
 regenerate them with golden_params() - and the reference's outputs), consumed by
 tests/test_oracle_vs_reference.py (CPU) and tests/test_gpu_model.py (HIP engine).
-Run from the repo root:   python tests/golden/make_reference_golden.py
+Run from the repo root:   python tests/golden/make_reference_golden.py          (tiny config)
+                          python tests/golden/make_reference_golden.py --v5     (fact_v5 dimensions, one sample)
 """
 import os
 import sys
@@ -165,5 +166,36 @@ def main():
           "AR frames", tuple(ref["ar"].shape))
 
 
+def main_v5():
+    """The same, at the REAL configuration (fact_v5_deeper_t10_cm12: d = 800, 10 heads of 80, ff = 3072, 2 + 2 + 12 layers,
+    120 + 240 tokens), one sample, float64: forward, loss, gradients by autograd through the reference's forward, and a
+    2-step auto-regressive rollout.  Written to tests/golden/reference_v5_golden.npz (predictions as float64; per-tensor
+    gradient norms and sums; the 120 M weights are regenerated from the seed by the tests and pinned by checksums)."""
+    sys.path.insert(0, ROOT)
+    from oracle import fact_oracle as O
+    cfg = O.FACT_V5_CFG
+    params = golden_params(O, cfg)
+    batch = O.synthetic_batch(cfg, 1, 20, seed=12)
+    ar_audio = torch.cat([batch["audio_input"], batch["audio_input"][:, :1]], dim=1)  # 241 frames: exactly 2 windows
+    ref = run_reference(cfg, params, batch["motion_input"], batch["audio_input"], batch["target"], ar_audio, 3,
+                        want_grads=True)
+    flat = torch.cat([params[n].reshape(-1) for n, _ in O.param_shapes(cfg)])
+    out = {
+        "params_sum": np.float64(flat.sum()), "params_abs_sum": np.float64(flat.abs().sum()),
+        "params_probe": flat[::999983].numpy(), "motion_input": batch["motion_input"].numpy(),
+        "audio_input": batch["audio_input"].numpy(), "target": batch["target"].numpy(), "ar_audio": ar_audio.numpy(),
+        "ref_pred": ref["pred"].numpy(), "ref_loss": np.float64(ref["loss"]), "ref_ar": ref["ar"].numpy(),
+        "ref_grad_norms": np.array([float(ref["grads"][n].norm()) for n, _ in O.param_shapes(cfg)]),
+        "ref_grad_sums": np.array([float(ref["grads"][n].sum()) for n, _ in O.param_shapes(cfg)]),
+    }
+    path = os.path.join(HERE, "reference_v5_golden.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes; reference loss", float(ref["loss"]),
+          "AR frames", tuple(ref["ar"].shape))
+
+
 if __name__ == "__main__":
-    main()
+    if "--v5" in sys.argv:
+        main_v5()
+    else:
+        main()

@@ -155,3 +155,68 @@ def test_fact_preprocessing_matches_reference_function(is_training, start):
         r = np.asarray(ref[k].as_subclass(torch.Tensor), dtype=np.float64)
         assert ours[k].shape == r.shape, k
         assert np.array_equal(np.asarray(ours[k], dtype=np.float64), r), k
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The same pin at the REAL configuration (fact_v5_deeper_t10_cm12 dimensions, one sample): the oracle's restatement
+# and the reference's model code agree where the GPU parity tests use the oracle (tests/test_gpu_model.py:
+# test_fact_v5_forward_and_grads_vs_oracle, test_fact_v5_autoregressive_vs_oracle).  float64; the two sum in different
+# orders at d = 800 / n = 360, hence a relative tolerance instead of the tiny config's 1e-12.
+# ---------------------------------------------------------------------------------------------------------------
+FIX_V5 = os.path.join(HERE, "golden", "reference_v5_golden.npz")
+RTOL_V5 = 1e-9
+
+
+@pytest.fixture(scope="module")
+def fx5():
+    d = np.load(FIX_V5)
+    params = G.golden_params(O, O.FACT_V5_CFG)
+    flat = torch.cat([params[n].reshape(-1) for n, _ in O.param_shapes(O.FACT_V5_CFG)])
+    assert flat.numel() == 120406977  # SURVEY 8a parameter inventory
+    assert abs(float(flat.sum()) - float(d["params_sum"])) < 1e-6
+    assert abs(float(flat.abs().sum()) - float(d["params_abs_sum"])) < 1e-6
+    assert np.array_equal(flat[::999983].numpy(), d["params_probe"])
+    return d, params
+
+
+def _rel(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def test_v5_forward_and_loss_match_reference_code(fx5):
+    d, params = fx5
+    pred = O.fact_forward(params, O.FACT_V5_CFG, _t(d["motion_input"]), _t(d["audio_input"]))
+    assert pred.shape == (1, 360, 225)
+    assert _rel(pred, _t(d["ref_pred"])) <= RTOL_V5
+    loss = float(O.motion_loss(_t(d["target"]), pred))
+    assert abs(loss - float(d["ref_loss"])) <= RTOL_V5 * abs(float(d["ref_loss"]))
+
+
+def test_v5_auto_regressive_matches_reference_code(fx5):
+    """3 steps requested, the 241-frame audio track admits 2 windows (early break of fact_model.py:124-126)."""
+    d, params = fx5
+    ar = O.infer_auto_regressive(params, O.FACT_V5_CFG, _t(d["motion_input"]), _t(d["ar_audio"]), steps=3)
+    assert ar.shape == (1, 2, 225)
+    assert _rel(ar, _t(d["ref_ar"])) <= RTOL_V5
+
+
+def test_v5_gradients_match_autograd_through_reference_forward(fx5):
+    d, params = fx5
+    _, grads, _ = O.loss_and_grads(params, O.FACT_V5_CFG, _t(d["motion_input"]), _t(d["audio_input"]), _t(d["target"]))
+    names = [n for n, _ in O.param_shapes(O.FACT_V5_CFG)]
+    assert len(names) == 184
+    norms = np.array([float(grads[n].norm()) for n in names])
+    sums = np.array([float(grads[n].sum()) for n in names])
+    assert np.allclose(norms, d["ref_grad_norms"], rtol=1e-8, atol=1e-14)
+    assert np.allclose(sums, d["ref_grad_sums"], rtol=1e-6, atol=1e-10)
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(G.REF, "mint", "core")), reason="reference checkout not present")
+def test_v5_reference_code_rerun_reproduces_fixture(fx5):
+    """Re-imports the reference and re-runs it at the fact_v5 dimensions (needs /root/reference; skipped on the GPU box)."""
+    d, params = fx5
+    ref = G.run_reference(O.FACT_V5_CFG, params, _t(d["motion_input"]), _t(d["audio_input"]), _t(d["target"]),
+                          _t(d["ar_audio"]), 3)
+    assert _rel(ref["pred"], _t(d["ref_pred"])) <= 1e-12
+    assert abs(float(ref["loss"]) - float(d["ref_loss"])) <= 1e-12 * abs(float(d["ref_loss"]))
+    assert _rel(ref["ar"], _t(d["ref_ar"])) <= 1e-12
