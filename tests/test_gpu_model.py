@@ -369,6 +369,47 @@ def test_engine_against_reference_code_vectors():
     assert np.all(np.abs(norms[big] - d["ref_grad_norms"][big]) / d["ref_grad_norms"][big] < 5e-2)
 
 
+def test_engine_against_reference_code_vectors_fact_v5():
+    """The same at the REAL configuration: tests/golden/reference_v5_golden.npz holds what the reference's own model
+    code computes at the fact_v5 dimensions (d = 800, 10 heads of 80, 2 + 2 + 12 layers, 120 + 240 tokens; one sample,
+    float64; make_reference_golden.py --v5).  Engine forward rel-Frobenius <= 2e-2, loss rel <= 1e-2, the 2-frame
+    auto-regressive rollout (3 requested, early break) rel <= 3e-2, per-tensor gradient norms within 5 %."""
+    import os
+    import sys
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, "golden"))
+    import make_reference_golden as G
+    d = np.load(os.path.join(here, "golden", "reference_v5_golden.npz"))
+    cfg = O.FACT_V5_CFG
+    params = G.golden_params(O, cfg)
+    model = model_builder.build(make_config(cfg), True)
+    model.build(1, 225, 35)
+    with torch.no_grad():
+        for n, v in zip(model.variable_names, model.trainable_variables):
+            v.copy_(params[n].to(torch.float32))
+    model.sync_weights()
+    dev = lambda k: torch.from_numpy(d[k]).float().cuda()
+    inp = {"motion_input": dev("motion_input"), "audio_input": dev("audio_input")}
+    out = model(inp)
+    assert tuple(out.shape) == (1, 360, 225)
+    assert rel(out, torch.from_numpy(d["ref_pred"])) < 2e-2, rel(out, torch.from_numpy(d["ref_pred"]))
+    loss = model.loss(dev("target"), out)
+    assert abs(float(loss) - float(d["ref_loss"])) / float(d["ref_loss"]) < 1e-2
+    ar = model.infer_auto_regressive({"motion_input": dev("motion_input"), "audio_input": dev("ar_audio")}, steps=3)
+    assert tuple(ar.shape) == (1, 2, 225)
+    assert rel(ar, torch.from_numpy(d["ref_ar"])) < 3e-2, rel(ar, torch.from_numpy(d["ref_ar"]))
+    model.grad_arena.zero_()
+    loss_fb = model.forward_backward(inp, dev("target"))
+    assert abs(float(loss_fb) - float(d["ref_loss"])) / float(d["ref_loss"]) < 1e-2
+    norms = np.array([float(g.norm()) for g in model.gradients])
+    big = d["ref_grad_norms"] > 1e-6
+    worst = float(np.max(np.abs(norms[big] - d["ref_grad_norms"][big]) / d["ref_grad_norms"][big]))
+    print("fact_v5 vs reference code: forward rel %.3e, AR rel %.3e, worst gradient-norm rel %.3e"
+          % (rel(out, torch.from_numpy(d["ref_pred"])), rel(ar, torch.from_numpy(d["ref_ar"])), worst))
+    assert worst < 5e-2, worst
+
+
 def test_headline_batch_big_tile_path_matches_128_tile_path():
     """At the headline shape (fact_v5, batch 16: 5760 tokens) the engine takes the big-tile GEMM kernels
     (288x256 tiles, staggered wave groups, LDS-staged epilogues) for the N = 3072 / 2400 GEMMs.  Forcing every
