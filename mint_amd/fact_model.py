@@ -107,6 +107,9 @@ class FACTModel:
         self._check_config(self._feat["motion"], self._feat["audio"])
         if self._h is not None and max_batch <= self._max_batch:
             return
+        if not torch.cuda.is_available():  # the product path has no CPU fallback: say so instead of a torch device error
+            raise RuntimeError("mint_amd runs on an AMD GPU (gfx950) through libfact_hip.so; torch.cuda.is_available() is "
+                               "False on this host and there is no CPU path")
         torch.cuda.set_device(self._device)
         cfg = self._cfg_struct()
         n_floats, n_tensors = C.c_size_t(0), C.c_int(0)
