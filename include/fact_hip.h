@@ -226,6 +226,7 @@ int fact_debug_attn_force_tiled(int on);
 /* Test/bench knob: attention kernel family. 1 (default) = one workgroup per (batch, head) with K/V resident in
  * LDS when they fit, tiled kernels otherwise; 2 = streaming 4-wave kernels (128-row blocks, LDS-DMA ring). */
 int fact_debug_attn_variant(int v);
+int fact_debug_attn_variant_get(void); /* the current family (tests restore it) */
 /* Bench only: device buffer of u64[B*H][waves][8] that receives per-wave s_memtime stamps of the LDS-resident
  * forward attention kernel (null = off). */
 int fact_debug_attn_timestamps(void* buf);

@@ -93,6 +93,7 @@ SIGNATURES = {
     "fact_debug_ln_bwd": (_i, [_i, _i]),
     "fact_debug_attn_force_tiled": (_i, [_i]),
     "fact_debug_attn_variant": (_i, [_i]),
+    "fact_debug_attn_variant_get": (_i, []),
     "fact_debug_attn_timestamps": (_i, [_vp]),
     "fact_debug_cu_hog": (_i, [_i, _i, _vp]),
 }

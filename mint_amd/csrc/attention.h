@@ -35,6 +35,10 @@ struct AttnParams {
 
 int launch_attn_fwd(const AttnParams& p, hipStream_t s);
 int launch_attn_bwd(const AttnParams& p, hipStream_t s);  // prep + dQ + dKdV
-void attn_set_variant(int v);  // 1 = LDS-resident / tiled kernels (default), 2 = streaming 4-wave kernels
+// kernel families (forward + backward): 1 = LDS-resident (tiled when the head does not fit), 2 = streaming 4-wave kernels,
+// 3 = streaming forward + resident backward, 4 = the reverse, 5 = streaming forward + lean resident backward (round 4),
+// 6 = resident forward + lean backward, 7 / 8 = 5 / 6 with packed fp32 softmax arithmetic in the backward
+void attn_set_variant(int v);
+int attn_get_variant();
 void attn_set_force_tiled(int on);
 void attn_set_ts(unsigned long long* buf);  // bench only: timestamp buffer, [B*H][waves][8]  // bench only: timing ablation bits of the streaming forward kernel  // test knob: 1 = tiled (streaming) kernels even when the LDS-resident ones fit

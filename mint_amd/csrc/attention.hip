@@ -1447,11 +1447,370 @@ __global__ __launch_bounds__(256, DH > 96 ? 1 : 2) void attn_bwd_dkdv_st_kernel(
   }
 }
 
+// =============================================================================================
+// Lean LDS-resident backward (round 4).  Same residency, fragment conventions and images as the
+// resident kernels above; what changes is everything that is not an MFMA in the tile loop:
+//   * no per-score masks: padded KEY rows of K / V are zero rows (attention.h), so a padded key
+//     contributes 0 * finite to dQ, and a padded key's dK / dV rows are simply never stored;
+//     padded / unsupervised QUERY rows are masked in the one query tile that holds them
+//     (wave-uniform branch), because the dO scratch is shared by stacks of different geometry;
+//   * dP - D comes out of the matrix pipe: the dP accumulator starts at -D[q] instead of 0;
+//   * the tile loop is unrolled four times over ONE per-lane LDS base per image, so every
+//     ds_read carries its tile / sub-tile / head-dim-step displacement in the 16-bit offset
+//     field instead of eight per-iteration v_add_u32 address updates;
+//   * template knob PK: the exponent FMA and dS = P o dP as packed fp32 pairs (attn_variant 7 / 8).
+// Per 32 x 32 score tile and wave: dQ 34 MFMA + 16 v_exp + ~40 VALU (was 126 + 16),
+// dK/dV 44 MFMA + 16 v_exp + ~50 VALU (was 148 + 16).
+// =============================================================================================
+template <int DHP>
+struct R2 {
+  static constexpr int ROWB = DHP * 2, TILE = 32 * ROWB, SUB = 16 * ROWB;
+};
+// per-lane byte offset of a row fragment inside a 16-row group of an img96 (add kd * 64, sub * SUB, tile * TILE)
+template <int DHP>
+DEVINL unsigned r2_row_off(int lane) {
+  const int r = lane & 15;
+  return (unsigned)(r * R2<DHP>::ROWB + (((lane >> 4) ^ res_g(r)) << 4));
+}
+// per-lane byte offsets of the token-contracting fragments of a 32-row tile: even / odd 16-dim tiles
+// (add (dt >> 1) * 64, tile * TILE; second half of the tokens at + SUB)
+template <int DHP>
+DEVINL void r2_tr_off(int lane, unsigned& e, unsigned& o) {
+  const int g = lane >> 4, s = lane & 15;
+  const int r = g * 4 + (s >> 2), low = ((s & 3) >> 1) ^ res_g(r);
+  e = (unsigned)(r * R2<DHP>::ROWB + low * 16 + (s & 1) * 8);
+  o = (unsigned)(r * R2<DHP>::ROWB + (low ^ 2) * 16 + (s & 1) * 8);
+}
+DEVINL bf16x8 r2_ld_row(const unsigned char* p) { return *reinterpret_cast<const bf16x8*>(p); }
+template <int SUB>
+DEVINL bf16x8 r2_ld_tr(const unsigned char* p) {
+  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(p + SUB));
+  return cat4(lo, hi);
+}
+// P = exp2(s * sc + nl) for this lane's 4 scores of one 16 x 16 sub-tile, then dS = P o dp (dp already holds dP - D);
+// nl = -L2[q]: one value per lane in the dQ kernel (queries are columns), one per register in dK/dV (queries are rows).
+// PK = 0: single v_fma_f32 / v_mul_f32.  Each result passes through an EMPTY asm statement: hipcc's SLP pass otherwise
+// pairs scores of DIFFERENT accumulators into v_pk_mul_f32 and pays for it with v_mov / v_perm / v_alignbit shuffles; the
+// arithmetic itself stays a compiler instruction (an asm v_fma reading an MFMA result would skip the MFMA -> VALU wait
+// states hipcc pads: measured NaN).  PK = 1: explicit aligned pairs (v_pk_fma_f32 / v_pk_mul_f32).
+DEVINL float r2_opaque(float x) {
+  asm("" : "+v"(x));
+  return x;
+}
+template <int PK>
+DEVINL void r2_p(const f32x4& s, float sc, const f32x4& nl, f32x4& pr) {
+  if constexpr (PK) {
+    const f32x2 sc2 = {sc, sc};
+    const f32x2 a = __builtin_elementwise_fma(f32x2{s[0], s[1]}, sc2, f32x2{nl[0], nl[1]});
+    const f32x2 b = __builtin_elementwise_fma(f32x2{s[2], s[3]}, sc2, f32x2{nl[2], nl[3]});
+    pr[0] = __builtin_amdgcn_exp2f(a[0]); pr[1] = __builtin_amdgcn_exp2f(a[1]);
+    pr[2] = __builtin_amdgcn_exp2f(b[0]); pr[3] = __builtin_amdgcn_exp2f(b[1]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f(r2_opaque(fmaf(s[r], sc, nl[r])));
+  }
+}
+template <int PK>
+DEVINL f32x4 r2_mul(const f32x4& a, const f32x4& b) {
+  if constexpr (PK) {
+    const f32x2 x = f32x2{a[0], a[1]} * f32x2{b[0], b[1]};
+    const f32x2 y = f32x2{a[2], a[3]} * f32x2{b[2], b[3]};
+    return f32x4{x[0], x[1], y[0], y[1]};
+  } else {
+    return f32x4{r2_opaque(a[0] * b[0]), r2_opaque(a[1] * b[1]), r2_opaque(a[2] * b[2]), r2_opaque(a[3] * b[3])};
+  }
+}
+
+template <int DH, int PK>
+__global__ __launch_bounds__(768) void attn_bwd_dq_r2_kernel(const AttnParams p) {
+  using G = Geo<DH>;
+  using R = R2<G::DHP>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, g = lane >> 4;
+  const int bh = blockIdx.x;
+  const int rows = (p.n + 31) & ~31;
+  const size_t img_bytes = ((size_t)rows * G::DHP * 2 + 1023) & ~(size_t)1023;
+  unsigned char* Kimg = smem;
+  unsigned char* Vimg = smem + img_bytes;
+  const size_t row_base = (size_t)bh * p.NP * G::DHP;
+  res_load<G::DHP, G::DHP / 8, true>(Kimg, p.krow + row_base, rows, wave, nw, lane);
+  res_load<G::DHP, G::DHP / 8, true>(Vimg, p.vrow + row_base, rows, wave, nw, lane);
+
+  const int q0 = wave * 32;
+  const int b = bh / p.H, h = bh - b * p.H;
+  if (p.nq > 0 && q0 >= p.nq) {
+    // supervised-rows shortcut: dO is zero on these query rows, so is dQ (the QKV dgrad reads every row)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const int t = q0 + qs * 16 + (lane & 15);
+      if (t < p.n) {
+        bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * p.ldq + h * DH + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt) *reinterpret_cast<bf16x4*>(orow + dt * 16) = bf16x4{};
+      }
+    }
+    return;
+  }
+  bf16x8 Qf[2][G::KD], dOf[2][G::KD];
+  float nL2[2], nD[2];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    const int q = q0 + qs * 16 + (lane & 15);
+    // D[q] = rowsum(dO o O): this lane holds 8 head columns of dO per 32-column slab, lanes g = 0..3 cover the slab
+    float part = 0.f;
+#pragma unroll
+    for (int kd = 0; kd < G::KD; ++kd) {
+      const size_t off = row_base + (size_t)q * G::DHP + kd * 32 + g * 8;
+      Qf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.qrow + off);
+      dOf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.dorow + off);
+      const int d0 = kd * 32 + g * 8;
+      if (q < p.n && d0 < DH) {
+        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(p.o + ((size_t)b * p.n + q) * p.ldo + h * DH + d0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += (float)dOf[qs][kd][j] * (float)ov[j];
+      }
+    }
+    part = st_allsum4(part);
+    nL2[qs] = -p.lse2[(size_t)bh * p.NP + q];
+    nD[qs] = -part;
+    if (g == 0) p.dsum[(size_t)bh * p.NP + q] = part;  // for the dK/dV kernel (0 on padded query rows)
+  }
+  f32x4 dQ[2][G::ND];
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+    for (int dt = 0; dt < G::ND; ++dt) dQ[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  unsigned trE, trO;
+  r2_tr_off<G::DHP>(lane, trE, trO);
+  const unsigned char* kr = Kimg + r2_row_off<G::DHP>(lane);  // per-lane bases, advanced 4 tiles at a time
+  const unsigned char* vr = Vimg + r2_row_off<G::DHP>(lane);
+  const unsigned char* ke = Kimg + trE;
+  const unsigned char* ko = Kimg + trO;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sc = p.scale * LOG2E;
+  const int nkt = rows >> 5;
+  auto body = [&](auto jc) {
+    constexpr int J = decltype(jc)::value;
+    f32x4 s[2][2], dp[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[ks][qs] = f32x4{nD[qs], nD[qs], nD[qs], nD[qs]};
+      }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kd = 0; kd < G::KD; ++kd) {
+        const bf16x8 kf = r2_ld_row(kr + J * R::TILE + ks * R::SUB + kd * 64);
+        const bf16x8 vf = r2_ld_row(vr + J * R::TILE + ks * R::SUB + kd * 64);
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+          s[ks][qs] = mfma16(kf, Qf[qs][kd], s[ks][qs]);
+          dp[ks][qs] = mfma16(vf, dOf[qs][kd], dp[ks][qs]);
+        }
+      }
+    bf16x8 dsb[2];
+#pragma unroll
+    for (int qs = 0; qs < 2; ++qs) {
+      const f32x4 nl = {nL2[qs], nL2[qs], nL2[qs], nL2[qs]};
+      f32x4 p0, p1;
+      r2_p<PK>(s[0][qs], sc, nl, p0);
+      r2_p<PK>(s[1][qs], sc, nl, p1);
+      dsb[qs] = pack8(r2_mul<PK>(p0, dp[0][qs]), r2_mul<PK>(p1, dp[1][qs]));
+    }
+#pragma unroll
+    for (int dt = 0; dt < G::ND; ++dt) {
+      const bf16x8 ktf = r2_ld_tr<R::SUB>(((dt & 1) ? ko : ke) + J * R::TILE + (dt >> 1) * 64);
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) dQ[qs][dt] = mfma16(ktf, dsb[qs], dQ[qs][dt]);
+    }
+  };
+  for (int kt = 0; kt < nkt; kt += 4) {
+    body(SlotK<0>{});
+    if (kt + 1 < nkt) body(SlotK<1>{});
+    if (kt + 2 < nkt) body(SlotK<2>{});
+    if (kt + 3 < nkt) body(SlotK<3>{});
+    kr += 4 * R::TILE; vr += 4 * R::TILE; ke += 4 * R::TILE; ko += 4 * R::TILE;
+  }
+#pragma unroll
+  for (int qs = 0; qs < 2; ++qs) {
+    const int t = q0 + qs * 16 + (lane & 15);
+    if (t < p.n) {
+      bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * p.ldq + h * DH + g * 4;
+#pragma unroll
+      for (int dt = 0; dt < G::ND; ++dt) {
+        bf16x4 o = {(bf16_t)(dQ[qs][dt][0] * p.scale), (bf16_t)(dQ[qs][dt][1] * p.scale),
+                    (bf16_t)(dQ[qs][dt][2] * p.scale), (bf16_t)(dQ[qs][dt][3] * p.scale)};
+        *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
+      }
+    }
+  }
+}
+
+// dK/dV: 8 waves (2 per SIMD), 32-key slots dealt round-robin; per slot the wave walks the query tiles.
+// The statistics live in LDS negated (-L2, -D): the dP accumulator starts from the loaded -D vector.
+template <int DH, int PK>
+__global__ __launch_bounds__(512) void attn_bwd_dkdv_r2_kernel(const AttnParams p) {
+  using G = Geo<DH>;
+  using R = R2<G::DHP>;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, g = lane >> 4;
+  const int bh = blockIdx.x;
+  const int rows = (p.n + 31) & ~31;
+  const size_t img_bytes = ((size_t)rows * G::DHP * 2 + 1023) & ~(size_t)1023;
+  unsigned char* Qimg = smem;
+  unsigned char* dOimg = smem + img_bytes;
+  float* nL2s = reinterpret_cast<float*>(smem + 2 * img_bytes);
+  float* nDs = nL2s + rows;
+  const size_t row_base = (size_t)bh * p.NP * G::DHP;
+  res_load<G::DHP, G::DHP / 8, true>(Qimg, p.qrow + row_base, rows, wave, nw, lane);
+  res_load<G::DHP, G::DHP / 8, true>(dOimg, p.dorow + row_base, rows, wave, nw, lane);
+  for (int i = tid; i < rows; i += blockDim.x) {
+    nL2s[i] = -p.lse2[(size_t)bh * p.NP + i];
+    nDs[i] = -p.dsum[(size_t)bh * p.NP + i];
+  }
+  unsigned trE, trO;
+  r2_tr_off<G::DHP>(lane, trE, trO);
+  const unsigned rowoff = r2_row_off<G::DHP>(lane);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float sc = p.scale * LOG2E;
+  const int nqt = rows >> 5;
+  const int nqv = (p.nq > 0 && p.nq < p.n) ? p.nq : p.n;  // valid query rows (supervised-rows shortcut: dO rows >= nq are zero)
+  const int nfull = nqv >> 5;  // query tiles without padded / unsupervised rows
+  const int b = bh / p.H, h = bh - b * p.H;
+  for (int slot = wave; slot < nqt; slot += nw) {
+    const int key0 = slot * 32;
+    bf16x8 Kf[2][G::KD], Vf[2][G::KD];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int kd = 0; kd < G::KD; ++kd) {
+        const size_t off = row_base + (size_t)(key0 + ks * 16 + (lane & 15)) * G::DHP + kd * 32 + g * 8;
+        Kf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.krow + off);
+        Vf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.vrow + off);
+      }
+    f32x4 dK[2][G::ND], dV[2][G::ND];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int dt = 0; dt < G::ND; ++dt) {
+        dK[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dV[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    const unsigned char* qr = Qimg + rowoff;
+    const unsigned char* dr = dOimg + rowoff;
+    const unsigned char* qe = Qimg + trE;
+    const unsigned char* qo = Qimg + trO;
+    const unsigned char* de = dOimg + trE;
+    const unsigned char* dd = dOimg + trO;
+    const float* st = nL2s + g * 4;  // this lane's 4 query rows of a 16-row sub-tile
+    const float* sd = nDs + g * 4;
+    // J: tile inside the group of four the bases point at; MASK: the one tile that holds padded / unsupervised query
+    // rows (peeled off the loop: the dO scratch is shared by stacks of different geometry, its padding is not zero)
+    auto body = [&](auto jc, auto mc, int qt) {
+      constexpr int J = decltype(jc)::value;
+      constexpr bool MASK = decltype(mc)::value != 0;
+      f32x4 nl[2], s[2][2], dp[2][2];  // [qsub][ksub]
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        nl[qs] = *reinterpret_cast<const f32x4*>(st + J * 32 + qs * 16);
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(sd + J * 32 + qs * 16);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s[qs][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
+          dp[qs][ks] = nd;
+        }
+      }
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int kd = 0; kd < G::KD; ++kd) {
+          const bf16x8 qf = r2_ld_row(qr + J * R::TILE + qs * R::SUB + kd * 64);
+          const bf16x8 df = r2_ld_row(dr + J * R::TILE + qs * R::SUB + kd * 64);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            s[qs][ks] = mfma16(qf, Kf[ks][kd], s[qs][ks]);
+            dp[qs][ks] = mfma16(df, Vf[ks][kd], dp[qs][ks]);
+          }
+        }
+      bf16x8 pb[2], dsb[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        f32x4 p0, p1;
+        r2_p<PK>(s[0][ks], sc, nl[0], p0);
+        r2_p<PK>(s[1][ks], sc, nl[1], p1);
+        if constexpr (MASK) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if ((qt * 32 + g * 4 + r) >= nqv) p0[r] = 0.f;
+            if ((qt * 32 + 16 + g * 4 + r) >= nqv) p1[r] = 0.f;
+          }
+        }
+        pb[ks] = pack8(p0, p1);
+        dsb[ks] = pack8(r2_mul<PK>(p0, dp[0][ks]), r2_mul<PK>(p1, dp[1][ks]));
+      }
+#pragma unroll
+      for (int dt = 0; dt < G::ND; ++dt) {
+        const bf16x8 dof = r2_ld_tr<R::SUB>(((dt & 1) ? dd : de) + J * R::TILE + (dt >> 1) * 64);
+        const bf16x8 qtf = r2_ld_tr<R::SUB>(((dt & 1) ? qo : qe) + J * R::TILE + (dt >> 1) * 64);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          dV[ks][dt] = mfma16(dof, pb[ks], dV[ks][dt]);
+          dK[ks][dt] = mfma16(qtf, dsb[ks], dK[ks][dt]);
+        }
+      }
+    };
+    for (int qt = 0; qt < nfull; qt += 4) {
+      body(SlotK<0>{}, SlotK<0>{}, qt);
+      if (qt + 1 < nfull) body(SlotK<1>{}, SlotK<0>{}, qt + 1);
+      if (qt + 2 < nfull) body(SlotK<2>{}, SlotK<0>{}, qt + 2);
+      if (qt + 3 < nfull) body(SlotK<3>{}, SlotK<0>{}, qt + 3);
+      qr += 4 * R::TILE; dr += 4 * R::TILE; qe += 4 * R::TILE; qo += 4 * R::TILE; de += 4 * R::TILE; dd += 4 * R::TILE;
+      st += 128; sd += 128;
+    }
+    if (nqv & 31) {
+      const int back = ((nfull + 3) & ~3) - nfull;  // the bases stand at the next multiple of four tiles
+      qr -= back * R::TILE; dr -= back * R::TILE; qe -= back * R::TILE; qo -= back * R::TILE; de -= back * R::TILE;
+      dd -= back * R::TILE; st -= back * 32; sd -= back * 32;
+      body(SlotK<0>{}, SlotK<1>{}, nfull);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int t = key0 + ks * 16 + (lane & 15);
+      if (t < p.n) {
+        bf16_t* krow_o = p.dqkv + ((size_t)b * p.n + t) * p.ldq + p.hid + h * DH + g * 4;
+        bf16_t* vrow_o = krow_o + p.hid;
+#pragma unroll
+        for (int dt = 0; dt < G::ND; ++dt) {
+          bf16x4 ok = {(bf16_t)(dK[ks][dt][0] * p.scale), (bf16_t)(dK[ks][dt][1] * p.scale),
+                       (bf16_t)(dK[ks][dt][2] * p.scale), (bf16_t)(dK[ks][dt][3] * p.scale)};
+          bf16x4 ov = {(bf16_t)dV[ks][dt][0], (bf16_t)dV[ks][dt][1], (bf16_t)dV[ks][dt][2],
+                       (bf16_t)dV[ks][dt][3]};
+          *reinterpret_cast<bf16x4*>(krow_o + dt * 16) = ok;
+          *reinterpret_cast<bf16x4*>(vrow_o + dt * 16) = ov;
+        }
+      }
+    }
+  }
+}
+
 // 1 = LDS-resident kernels when the head fits (tiled otherwise), 2 = streaming family, 3 = streaming forward + resident
 // backward (default, round 3: the forward runs alone on the chip, where the 480-workgroup streaming kernel is 4 us
 // shorter; the backward kernels run beside the 95-workgroup wgrad launches, where the 160-workgroup resident ones leave
-// it the CUs - same-box A/B of the step: 7.97-7.99 / 7.94-7.95 / 7.87-7.90 / 8.00-8.01 ms for 1 / 2 / 3 / 4), 4 = the reverse
-int g_attn_variant = 3;
+// it the CUs - same-box A/B of the step: 7.97-7.99 / 7.94-7.95 / 7.87-7.90 / 8.00-8.01 ms for 1 / 2 / 3 / 4), 4 = the reverse,
+// 5 (default, round 4) = streaming forward + LEAN resident backward (kernels above: dQ 30.0 -> 26.9 us, dK/dV 32.9 -> 26.7 us
+// alone, 38.2 -> 32.5 us per launch in the step, step 7.64 -> 7.58 ms same box), 6 = resident forward + lean backward,
+// 7 / 8 = 5 / 6 with packed fp32 softmax arithmetic (28.1 / 27.8 us: v_pk_* issue half as often but run twice as long)
+int g_attn_variant = 5;
 int g_attn_force_tiled = 0;  // test knob: 1 = always use the tiled (streaming) kernels
 
 // LDS bytes of the resident kernels for n tokens; 0 = does not fit -> tiled kernels
@@ -1501,17 +1860,27 @@ int allow_lds_bytes(K kernel, bool* done, size_t bytes) {
   return 0;
 }
 
+// does launch_attn_bwd run the LDS-resident kernels (old or lean) for n tokens?  They honour AttnParams::nq; the
+// streaming backward (variants 2 / 4, or whatever the resident kernels cannot hold) does not.
+template <int DH>
+bool bwd_is_resident(int n) {
+  return g_attn_variant != 2 && g_attn_variant != 4 && !g_attn_force_tiled && res_lds_bytes<DH>(n, 1) &&
+         res_lds_bytes<DH>(n, 2);
+}
+
 template <int DH>
 int fwd_t(const AttnParams& p, hipStream_t s) {
   // streaming kernel: the default forward; also whatever the resident kernels cannot hold (head dims above 96, n > 384)
-  if ((g_attn_variant == 2 || g_attn_variant == 3 || !res_lds_bytes<DH>(p.n, 0)) && !g_attn_force_tiled) {
+  if ((g_attn_variant == 2 || g_attn_variant == 3 || g_attn_variant == 5 || g_attn_variant == 7 ||
+       !res_lds_bytes<DH>(p.n, 0)) &&
+      !g_attn_force_tiled) {
     constexpr size_t lds = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG;
     static bool attr = false;
     if (int rc = allow_lds_bytes(attn_fwd_st_kernel<DH>, &attr, lds)) return rc;
     // supervised-rows shortcut: only where the backward that may follow is nq-aware too (the resident kernels; the streaming
     // backward reads the log-sum-exp of every row)
     AttnParams q = p;
-    if (!(res_lds_bytes<DH>(p.n, 1) && res_lds_bytes<DH>(p.n, 2))) q.nq = 0;
+    if (!bwd_is_resident<DH>(p.n)) q.nq = 0;
     const int nqv = (q.nq > 0 && q.nq < q.n) ? q.nq : q.n;
     hipLaunchKernelGGL(attn_fwd_st_kernel<DH>, dim3((nqv + 127) / 128, q.B * q.H), dim3(256), lds, s, q);
     return 0;
@@ -1521,7 +1890,9 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
     static bool attr = false;
     if (int rc = allow_big_lds(attn_fwd_res_kernel<DH>, &attr)) return rc;
     const int nw = ((p.n + 31) & ~31) / 32;
-    hipLaunchKernelGGL(attn_fwd_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds, s, p);
+    AttnParams q = p;
+    if (!bwd_is_resident<DH>(p.n)) q.nq = 0;  // variant 4: the streaming backward reads every row's log-sum-exp
+    hipLaunchKernelGGL(attn_fwd_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds, s, q);
     return 0;
   }
   dim3 grid((p.n + 127) / 128, p.B * p.H);
@@ -1530,8 +1901,7 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
 }
 template <int DH>
 int bwd_t(const AttnParams& p, hipStream_t s) {
-  if ((g_attn_variant == 2 || g_attn_variant == 4 || !res_lds_bytes<DH>(p.n, 1) || !res_lds_bytes<DH>(p.n, 2)) &&
-      !g_attn_force_tiled) {
+  if (!bwd_is_resident<DH>(p.n) && !g_attn_force_tiled) {
     constexpr size_t lds1 = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG, lds2 = (size_t)SG<DH>::NSLOT * (2 * SG<DH>::IMG + 256);
     static bool attr1 = false, attr2 = false;
     if (int rc = allow_lds_bytes(attn_bwd_dq_st_kernel<DH>, &attr1, lds1)) return rc;
@@ -1548,14 +1918,31 @@ int bwd_t(const AttnParams& p, hipStream_t s) {
   const int nw = ((p.n + 31) & ~31) / 32;
   dim3 grid((p.n + 127) / 128, p.B * p.H);
   if constexpr (DH <= 96) {
-    if (lds1) {
+    const bool r2 = g_attn_variant >= 5, pk = g_attn_variant >= 7;
+    if (lds1 && r2 && pk) {
+      static bool attr = false;
+      if (int rc = allow_big_lds(attn_bwd_dq_r2_kernel<DH, 1>, &attr)) return rc;
+      hipLaunchKernelGGL((attn_bwd_dq_r2_kernel<DH, 1>), dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
+    } else if (lds1 && r2) {
+      static bool attr = false;
+      if (int rc = allow_big_lds(attn_bwd_dq_r2_kernel<DH, 0>, &attr)) return rc;
+      hipLaunchKernelGGL((attn_bwd_dq_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
+    } else if (lds1) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dq_res_kernel<DH>, &attr)) return rc;
       hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
     } else {
       hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
     }
-    if (lds2) {
+    if (lds2 && r2 && pk) {
+      static bool attr = false;
+      if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 1>, &attr)) return rc;
+      hipLaunchKernelGGL((attn_bwd_dkdv_r2_kernel<DH, 1>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
+    } else if (lds2 && r2) {
+      static bool attr = false;
+      if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 0>, &attr)) return rc;
+      hipLaunchKernelGGL((attn_bwd_dkdv_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
+    } else if (lds2) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dkdv_res_kernel<DH>, &attr)) return rc;
       hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel<DH>, dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
@@ -1573,6 +1960,7 @@ int bwd_t(const AttnParams& p, hipStream_t s) {
 
 void attn_set_force_tiled(int on) { g_attn_force_tiled = on; }
 void attn_set_variant(int v) { g_attn_variant = v; }
+int attn_get_variant() { return g_attn_variant; }
 
 unsigned long long* g_attn_ts = nullptr;
 void attn_set_ts(unsigned long long* buf) { g_attn_ts = buf; }

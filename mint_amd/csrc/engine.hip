@@ -2259,6 +2259,7 @@ int fact_debug_attn_variant(int v) {
   attn_set_variant(v);
   return 0;
 }
+int fact_debug_attn_variant_get(void) { return attn_get_variant(); }
 int fact_debug_gemm_nt_variant(int v) {
   gemm_set_nt_variant(v);
   return 0;

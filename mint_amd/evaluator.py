@@ -1,27 +1,39 @@
 """Evaluation loop: mirror of mint/ctl/single_task_evaluator.py (row f1).  One eval step runs the
 device-resident auto-regressive sampler for `steps` frames, prepends the seed motion and saves one
 `{motion_name}_{audio_name}.npy` of shape (seed + generated, 225) per sample — the file contract
-`tools/calculate_scores.py:210-215` consumes."""
+`tools/calculate_scores.py:210-215` consumes.
+
+Under one-process-per-GPU data parallelism every rank takes its contiguous share of each global eval batch
+(mint_amd/sharding.py; the reference's `strategy.run` does the same split, single_task_evaluator.py:86) and saves its own
+files; no collective runs while sequences are generated."""
 import os
 
 import numpy as np
 import torch
 
+from mint_amd import sharding
+
 
 class SingleTaskEvaluator:
-    def __init__(self, eval_dataset, model, metrics=None, output_dir=None, evaluator_options=None, steps=1200):
+    def __init__(self, eval_dataset, model, metrics=None, output_dir=None, evaluator_options=None, steps=1200,
+                 rank=None, world_size=None):
         self.eval_dataset = eval_dataset
         self.model = model
         self.metrics = [] if metrics is None else (metrics if isinstance(metrics, list) else [metrics])
         self.output_dir = output_dir
         self.steps = steps
+        # data-parallel evaluation: (rank, world) of the default process group unless given
+        self.rank, self.world_size = (rank, world_size) if rank is not None and world_size is not None else (
+            sharding.world_info())
 
     def eval_begin(self):
         for metric in self.metrics:
             metric.reset_states()
 
     def eval_step(self, iterator):
-        inputs = next(iterator)
+        inputs = sharding.shard_inputs(next(iterator), self.rank, self.world_size)  # this replica's sequences
+        if int(inputs["motion_input"].shape[0]) == 0:
+            return None, []  # more ranks than sequences in this batch
         # [batch, steps, dim] -> [batch, seed + steps, dim]   (single_task_evaluator.py:69-71)
         outputs = self.model.infer_auto_regressive(inputs, steps=self.steps)
         seed = torch.as_tensor(inputs["motion_input"]).to(outputs.device, outputs.dtype)

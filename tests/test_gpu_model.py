@@ -24,9 +24,10 @@ def continuous_attention():
     a 1-ulp weight difference flips such a decision: 4e-9 -> 3e-3 relative output difference, measured); the LDS-resident
     family has no such threshold."""
     from mint_amd import _lib as L
+    before = L.lib().fact_debug_attn_variant_get()
     L.lib().fact_debug_attn_variant(1)
     yield
-    L.lib().fact_debug_attn_variant(3)
+    L.lib().fact_debug_attn_variant(before)
 
 
 def make_config(cfg):

@@ -412,16 +412,18 @@ def _attn_ref(qkv, B, H, n, dh, scale, dout=None):
     return out.detach(), x.grad
 
 
-@pytest.fixture(params=[0, 1, 2], ids=["resident", "tiled", "streaming"])
+@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["resident", "tiled", "streaming", "lean", "lean_pk"])
 def attn_path(request):
-    """The three kernel families: LDS-resident (when the head fits), tiled, and the streaming 4-wave kernels
-    (128-row blocks, 4-slot LDS-DMA ring, lazy-max softmax with MFMA row sums)."""
+    """The kernel families: LDS-resident (when the head fits), tiled, the streaming 4-wave kernels (128-row blocks,
+    4-slot LDS-DMA ring, lazy-max softmax with MFMA row sums), and the lean LDS-resident backward of round 4 (behind the
+    streaming forward = the engine's default pairing), with scalar and with packed fp32 softmax arithmetic."""
     lib = L.lib()
+    before = lib.fact_debug_attn_variant_get()
     lib.fact_debug_attn_force_tiled(1 if request.param == 1 else 0)
-    lib.fact_debug_attn_variant(2 if request.param == 2 else 1)
+    lib.fact_debug_attn_variant({0: 1, 1: 1, 2: 2, 3: 5, 4: 7}[request.param])
     yield request.param
     lib.fact_debug_attn_force_tiled(0)
-    lib.fact_debug_attn_variant(1)
+    lib.fact_debug_attn_variant(before)
 
 
 @pytest.mark.parametrize("B,H,n,dh", [(2, 4, 32, 32), (1, 2, 96, 64), (2, 10, 360, 80), (2, 10, 120, 80),
