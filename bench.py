@@ -14,7 +14,7 @@ RCCL gradient all-reduce (N>1), Keras-Adam update, bf16 weight-shadow refresh.  
   * `roofline`: the DOMINANT class of that table (largest time share);
   * `attention`: the cross-modal attention sub-row the north star names (forward / backward TFLOP/s);
   * `cpu_baseline`: the oracle (PyTorch-CPU fp32 restatement of the reference train step) timed on this box's
-    host cores at N=1: 1 warm-up + 2 timed steps at batch 4.
+    host cores at N=1: 1 warm-up + 2-3 timed steps at the per-GPU batch of 16 (a batch-4 sample as a side note).
 
 Other modes (artefacts for profiles/, not the driver's line):
   --mode ar      BASELINE.json configs[3] per-GPU share: 32 sequences, 120-frame seed, --steps generated frames
@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)   # >= 50 timed steps after >= 10 warm-up
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 16 train, 32 ar, 8 scaled)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="--mode ar: total sequences over all ranks (strong scaling, e.g. 256 = configs[3]); default "
+                         "--batch per GPU (weak scaling: 256 at N = 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print a per-phase timing to stderr")
     ap.add_argument("--side-stream", type=int, default=1, help="0 = single-stream engine (A/B knob)")
@@ -80,33 +83,31 @@ def parse():
                          "hardware queues (GPU_MAX_HW_QUEUES = 7; an 8th busy queue doubled the step in the one-GPU dry "
                          "run, profiles/r02_dp_dry_run.txt) at ~0.2 ms per step")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
-                    help="engine option for A/B runs (fact_set_option), e.g. --opt wgrad_parts=1")
+                    help="engine test / bench knob for A/B runs (fact_debug_set_option), e.g. --opt wgrad_parts=1")
     return ap.parse_args()
 
 
 PEAK_HBM_GBS = 8000.0         # MI355X HBM3E (MI355X_MICROARCH.md)
-# kernel symbols behind each class of the engine's in-step table (for matching against rocprofv3 summaries)
-KERNEL_SYMBOLS = {
-    "wgrad_group": "big_tn_kernel<BigCfg<2,5,4,4,4,1>, 0> (160x256 whole-K tiles, grouped: 4 wgrads of a layer, 2 launches of 95)",
-    "ffn1+gelu": "big_nt_kernel<BigCfg<2,9,4,4,4,1>, EPI_BIAS_GELU> (288x256 tiles)",
-    "gelu'_dgrad": "big_nt_kernel<BigCfg<2,9,4,4,4,1>, EPI_GELU_BWD> (288x256 tiles)",
-    "qkv_gemm+heads": "big_nt_kernel<BigCfg<2,8,4,4,4,1>, EPI_HEADS> (256x256 tiles)",
-    "ffn2+resid": "big_nt_kernel<BigCfg<4,4,2,5,4,1>, EPI_F32_BIAS_RESID> (256x160 tiles, in-kernel split-K 2)",
-    "out_proj+resid": "big_nt_kernel<BigCfg<4,4,2,4,3,2>, EPI_F32_BIAS_RESID> (256x128 tiles, 2 workgroups per CU)",
-    "ffn1_dgrad": "big_nt_kernel<BigCfg<4,4,2,5,4,1>, EPI_BF16> (256x160 tiles, whole K)",
-    "qkv_dgrad": "big_nt_kernel<BigCfg<4,4,2,5,4,1>, EPI_BF16> (256x160 tiles, whole K)",
-    "out_proj_dgrad+heads": "big_nt_kernel<BigCfg<4,4,2,4,3,2>, EPI_HEADS> (256x128 tiles, 2 workgroups per CU)",
-    "attention_fwd": "attn_fwd_st_kernel<80> (streaming, 480 workgroups)",
-    "attention_bwd": "attn_bwd_dq_res_kernel<80> + attn_bwd_dkdv_res_kernel<80> (LDS-resident, 160 workgroups each)",
-    "ln_fwd": "ln_fwd_kernel<4>", "ln_bwd_dx": "ln_bwd_dx_kernel<4>", "bias/ln_param_grads": "col_tasks_kernel",
-    "adam+shadows": "adam_fused2_kernel<64,false>",
-}
-# CUs a launch of the class can hold at fact_v5 / B = 16 (workgroups of the cross-modal launch, capped at 256; big-tile
-# kernels run one workgroup per CU, the 256x128 config two): the whole-chip `frac` of a class that is deliberately
-# given part of the chip understates the kernel - `frac_of_held_cus` = frac / cu_share is the per-CU figure
-CLASS_CUS = {"wgrad_group": 95, "ffn1+gelu": 240, "gelu'_dgrad": 240, "qkv_gemm+heads": 230, "ffn2+resid": 230,
-             "out_proj+resid": 81, "ffn1_dgrad": 115, "qkv_dgrad": 115, "out_proj_dgrad+heads": 81,
-             "attention_fwd": 256, "attention_bwd": 160}
+N_CUS = 256
+
+
+def class_kernels(rec):
+    """What the engine's recorder saw behind one class of the table (FACT_LAUNCH notes, fact_kprof_kernels): the symbol
+    of the most frequent launch shape exactly as rocprofv3 prints it (the cross-modal layers outnumber the encoder
+    layers 12 : 4, so this is the cross-modal launch), its grid, and the CUs that grid can hold -
+    min(256, ceil(grid / workgroups per CU)) with the runtime's occupancy answer for the launch shape."""
+    ks = rec.get("kernels") or []
+    if not ks:
+        return {"kernel": rec["name"], "cu_share": None}
+    top = ks[0]
+    names = []
+    for k in ks:  # distinct symbols of the class, most frequent first (attention backward: dQ and dK/dV kernels)
+        if k["name"] not in names:
+            names.append(k["name"])
+    per_cu = max(1, top["workgroups_per_cu"])
+    cus = min(N_CUS, -(-top["grid"] // per_cu))
+    return {"kernel": " + ".join(names[:2]), "grid": top["grid"], "block": top["block"], "lds_bytes": top["lds_bytes"],
+            "workgroups_per_cu": top["workgroups_per_cu"], "cus_held": cus, "cu_share": round(cus / N_CUS, 3)}
 
 
 def kernel_table(model, step_fn, nsteps):
@@ -124,7 +125,9 @@ def kernel_table(model, step_fn, nsteps):
     for r in recs:
         if r["launches"] <= 0:
             continue
-        row = {"name": r["name"], "kernel": KERNEL_SYMBOLS.get(r["name"], r["name"]),
+        ck = class_kernels(r)
+        row = {"name": r["name"], "kernel": ck["kernel"], "grid": ck.get("grid"),
+               "workgroups_per_cu": ck.get("workgroups_per_cu"),
                "launches_per_step": round(r["launches"] / nsteps, 1),
                "avg_launch_us": round(r["total_ms"] * 1e3 / r["launches"], 2),
                "ms_per_step": round(r["total_ms"] / nsteps, 3),
@@ -133,9 +136,10 @@ def kernel_table(model, step_fn, nsteps):
             tf = r["flops"] / (r["total_ms"] * 1e-3) / 1e12
             row.update(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                        frac=round(tf / PEAK_BF16_TFLOPS, 4), flop_per_launch=r["flops"] / r["launches"])
-            if r["name"] in CLASS_CUS:
-                share = CLASS_CUS[r["name"]] / 256.0
-                row.update(cu_share=round(share, 3), frac_of_held_cus=round(tf / PEAK_BF16_TFLOPS / share, 4))
+            if ck.get("cu_share"):
+                # the whole-chip `frac` of a class that is deliberately given part of the chip understates the kernel:
+                # frac_of_held_cus = frac / cu_share is the per-CU figure
+                row.update(cu_share=ck["cu_share"], frac_of_held_cus=round(tf / PEAK_BF16_TFLOPS / ck["cu_share"], 4))
         else:
             gbs = r["bytes"] / (r["total_ms"] * 1e-3) / 1e9
             row.update(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s",
@@ -212,44 +216,44 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(B=4, timed=2, budget_s=10.0, max_timed=16, b16_check=True):
-    """Oracle (PyTorch-CPU fp32 restatement of the reference train step: forward, loss, backward, Keras Adam)
-    on a bounded sample of the same workload: fact_v5 at batch 4 (a quarter of the per-GPU batch; the fp32 GEMMs
-    of the oracle are large enough at 1440 tokens that frames/s does not depend on the batch), 1 warm-up step
-    + at least `timed` timed steps - as many as fit into `budget_s` seconds - on all usable host cores."""
-    from oracle import fact_oracle as O
-    cores = min(usable_cores(), 64)
-    torch.set_num_threads(cores)
-    cfg = O.FACT_V5_CFG
+def _time_oracle(O, cfg, B, timed, budget_s, max_timed):
+    """1 warm-up + >= `timed` timed oracle train steps at batch B (as many as fit into budget_s, at most max_timed);
+    returns (frames per second, seconds timed, steps timed, warm-up seconds)."""
     params = O.init_params(cfg, seed=0, dtype=torch.float32)
     batch = O.synthetic_batch(cfg, B, TARGET_LEN, seed=0, dtype=torch.float32)
     m = {k: torch.zeros_like(v) for k, v in params.items()}
     v = {k: torch.zeros_like(x) for k, x in params.items()}
-    step = 0
     t_warm = time.perf_counter()
-    params, m, v = _oracle_step(O, params, m, v, step, cfg, batch)
+    params, m, v = _oracle_step(O, params, m, v, 0, cfg, batch)
     t_warm = time.perf_counter() - t_warm
-    if t_warm > 20.0:  # very slow host: report the warm-up step itself rather than blow the time budget
-        dt, n, note = t_warm, 1, "1 (cold) train step"
-    else:
-        t0 = time.perf_counter()
-        n = 0
-        while n < timed or (n < max_timed and time.perf_counter() - t0 < budget_s):
-            params, m, v = _oracle_step(O, params, m, v, step + 1 + n, cfg, batch)
-            n += 1
-        dt, note = time.perf_counter() - t0, "1 warm-up + %d timed train steps" % n
-    out = {"value": round(n * B * 120 / dt, 2), "unit": "motion frames/sec", "cores": cores, "kind": "port",
-           "sample": "%s of fact_v5 at batch %d (%.1f s timed; fp32 PyTorch-CPU oracle, %d threads)" % (
-               note, B, dt, cores)}
-    if b16_check and t_warm <= 20.0:
-        # SURVEY 8(d) names the per-GPU batch of 16: ONE cold step at that batch beside the bounded batch-4 sample
-        batch16 = O.synthetic_batch(cfg, 16, TARGET_LEN, seed=1, dtype=torch.float32)
-        t0 = time.perf_counter()
-        _oracle_step(O, params, m, v, step + 1 + n, cfg, batch16)
-        t16 = time.perf_counter() - t0
-        out["batch16_one_step"] = {"seconds": round(t16, 2), "frames_per_sec": round(16 * 120 / t16, 2),
-                                   "note": "one un-warmed train step at the per-GPU batch of 16 (first touch of the batch-16 "
-                                           "activations included)"}
+    if t_warm > 30.0:  # very slow host: report the warm-up step itself rather than blow the time budget
+        return B * 120 / t_warm, t_warm, 0, t_warm
+    t0 = time.perf_counter()
+    n = 0
+    while n < timed or (n < max_timed and time.perf_counter() - t0 < budget_s):
+        params, m, v = _oracle_step(O, params, m, v, 1 + n, cfg, batch)
+        n += 1
+    dt = time.perf_counter() - t0
+    return n * B * 120 / dt, dt, n, t_warm
+
+
+def cpu_baseline():
+    """Oracle (PyTorch-CPU fp32 restatement of the reference train step: forward, loss, backward, Keras Adam) on a
+    bounded sample of the same workload, on all usable host cores: `value` = fact_v5 at the per-GPU batch of 16 that
+    SURVEY 8(d) names, 1 warm-up + 2-3 timed steps (~15 s of CPU work); a batch-4 sample (1 warm-up + 2 timed steps)
+    rides along as a side note - the two differ by what the host's caches make of the 4x larger activations."""
+    from oracle import fact_oracle as O
+    cores = min(usable_cores(), 64)
+    torch.set_num_threads(cores)
+    cfg = O.FACT_V5_CFG
+    fps, dt, n, warm = _time_oracle(O, cfg, BATCH_PER_GPU, timed=2, budget_s=10.0, max_timed=3)
+    note = ("1 warm-up + %d timed train steps" % n) if n else "1 (cold) train step"
+    out = {"value": round(fps, 2), "unit": "motion frames/sec", "cores": cores, "kind": "port",
+           "sample": "%s of fact_v5 at batch %d (%.1f s timed, warm-up %.1f s; fp32 PyTorch-CPU oracle, %d threads)" % (
+               note, BATCH_PER_GPU, dt, warm, cores)}
+    if n:
+        fps4, dt4, n4, _ = _time_oracle(O, cfg, 4, timed=2, budget_s=2.0, max_timed=4)
+        out["batch4_sample"] = {"frames_per_sec": round(fps4, 2), "seconds": round(dt4, 2), "timed_steps": n4}
     return out
 
 
@@ -270,30 +274,110 @@ def class_table(model, psteps):
             for r in sorted(recs, key=lambda r: -r["total_ms"]) if r["launches"] > 0]
 
 
-def run_ar(args, device):
-    """BASELINE.json configs[3], per-GPU share: 32 sequences, 120-frame seed, `steps` generated frames each
-    (full forward per frame: no KV cache is possible, fact_model.py:103-132)."""
-    from mint_amd import configs, model_builder
-    B = args.batch or 32
+def sync_all(world):
+    """Barrier over the ranks + device drain: both sides of every timed region."""
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(dt, world, device, dry):
+    """The job's time is the slowest rank's (MAX all-reduce; through the host under the gloo dry run)."""
+    if world == 1:
+        return dt
+    import torch.distributed as dist
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if dry else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def apply_opts(model, args):
+    for kv in args.opt:
+        k, v = kv.split("=")
+        model.debug_option(k, int(v))
+
+
+def make_trainer(model, batch, opt, args, world):
+    """The data-parallel train-step structure of every training mode: summed bucketed all-reduce of the gradient arena
+    on a communication stream overlapped with backward (bf16 buckets unless --grad-buckets fp32), Adam of a bucket
+    behind its all-reduce; at N = 1 the single-replica step (optimizer inside backward)."""
+    from mint_amd.trainer import SingleTaskTrainer
+
+    class Repeat:
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            return batch
+    trainer = SingleTaskTrainer(Repeat(), "target", model, optimizer=opt, fuse_optimizer=bool(args.fuse_optimizer),
+                                bf16_grad_buckets=(world > 1 and args.grad_buckets == "bf16"),
+                                overlap_grad_allreduce=(True if world > 1 else None))
+    return trainer, iter(Repeat())
+
+
+def timed_train_steps(trainer, it, args, world, device, dry):
+    """W untimed warm-up steps, then exactly K steps between (barrier + synchronize) pairs; MAX over ranks."""
+    trainer.train_loop_begin()
+    for _ in range(args.warmup):
+        trainer.train_step(it)
+    sync_all(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.train_step(it)
+    sync_all(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, device, dry)
+    return dt, float(loss)
+
+
+def comm_record(trainer, it, args, world):
+    """Per-bucket all-reduce time and exposed communication of the N > 1 step (after the timed region)."""
+    if world == 1 or getattr(trainer, "_reducer", None) is None:
+        return None
+    trainer._reducer.profile = True
+    for _ in range(max(1, args.profile_steps)):
+        trainer.train_step(it)
+    comm = trainer._reducer.comm_report()
+    trainer._reducer.profile = False
+    return comm
+
+
+def run_ar(args, device, world=1, rank=0, dry=False):
+    """BASELINE.json configs[3]: auto-regressive generation, 120-frame seed -> `steps` frames per sequence (full
+    forward per frame: no KV cache is possible, fact_model.py:103-132).  The global batch of sequences
+    (--global-batch; default 32 per GPU, i.e. the 256 of configs[3] at N = 8) is sharded over the ranks with NO
+    collective while sequences are generated (mint_amd/sharding.py): rank r generates sequences
+    [r*G/N, (r+1)*G/N) of the same seeded global input; afterwards ONE all-gather collects the (G, steps, 225) result and
+    rank 0 checks it."""
+    from mint_amd import configs, model_builder, sharding
+    per = args.batch or 32
+    G = args.global_batch or per * world
+    lo, hi = sharding.shard_range(G, rank, world)
+    B = hi - lo
     steps = args.steps
     pipe = configs.fact_v5_deeper_t10_cm12()
     model = model_builder.build(pipe.multi_modal_model, False)
     gen = torch.Generator().manual_seed(7)
-    inp = {"motion_input": torch.randn(B, 120, 225, generator=gen).to(device),
-           "audio_input": torch.randn(B, 240 + steps - 1, 35, generator=gen).to(device)}
+    glob = {"motion_input": torch.randn(G, 120, 225, generator=gen),
+            "audio_input": torch.randn(G, 240 + steps - 1, 35, generator=gen)}
+    inp = {k: v.to(device) for k, v in sharding.shard_inputs(glob, rank, world).items()}
+    del glob
     model.build(B, 225, 35)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        model.set_option(k, int(v))
+    apply_opts(model, args)
     model.infer_auto_regressive(inp, steps=min(steps, max(1, args.warmup)))
-    torch.cuda.synchronize()
+    sync_all(world)
     t0 = time.perf_counter()
     out = model.infer_auto_regressive(inp, steps=steps)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    sync_all(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, device, dry)
     assert out.shape == (B, steps, 225)
+    full = sharding.gather_rows(out, G, rank, world)  # after the timed region: the only communication of the path
+    gathered = {"shape": list(full.shape), "finite": bool(torch.isfinite(full).all()),
+                "rms": round(float(full.double().pow(2).mean().sqrt()), 5)}
+    assert tuple(full.shape) == (G, steps, 225) and gathered["finite"], gathered
+    del full
     parity = None
-    if args.parity:
+    if args.parity and rank == 0:
         # the same generation with the one-kept-row last layer and the split-K small-M GEMMs switched off (sr_rows = 0):
         # every frame of the full-length rollout finite, and the two rollouts equal frame range by frame range
         model.set_option("sr_rows", 0)
@@ -308,61 +392,59 @@ def run_ar(args, device):
                                               for a, b in zip(edges[:-1], edges[1:]) if b > a and b <= steps},
                   "rms_output": round(float(out.double().pow(2).mean().sqrt()), 5),
                   "reference": "same engine, sr_rows = 0 (all 360 rows through the last layer, single-pass GEMMs)"}
-    fwd_flop = 80.97e9 * B  # BASELINE.md section 2, forward FLOPs per sample
+    fwd_flop = 80.97e9 * G  # BASELINE.md section 2, forward FLOPs per sample
     # kernel classes of the sampler (engine event recorder, outside the timed region): ms per generated frame-step
     kern = None
-    if args.profile_steps > 0:
+    if args.profile_steps > 0 and rank == 0:
         psteps = min(args.profile_steps, steps)
         model.kernel_profile(True)
         model.infer_auto_regressive(inp, steps=psteps)
         kern = class_table(model, psteps)
-    print(json.dumps({
+    if world > 1:
+        sync_all(world)
+    if rank != 0:
+        return
+    out_line = {
         "metric": "generated motion frames/sec (auto-regressive inference) fact_v5_deeper_t10_cm12",
-        "value": round(B * steps / dt, 1), "unit": "generated frames/sec", "n_gpus": 1, "steps": steps,
+        "value": round(G * steps / dt, 1), "unit": "generated frames/sec", "n_gpus": world, "steps": steps,
         "warmup": args.warmup, "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "AR inference 120-frame seed -> %d frames (BASELINE.json configs[3], per-GPU share)" % steps,
-                   "per_gpu_batch": B, "audio_frames": 240 + steps - 1},
+        "scaling": "weak" if not args.global_batch else "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "AR inference 120-frame seed -> %d frames (BASELINE.json configs[3])" % steps,
+                   "global_sequences": G, "per_gpu_batch": B, "audio_frames": 240 + steps - 1,
+                   "parallelism": "dp%d: sequences sharded by rank, no collective while generating, one all-gather of the "
+                                  "(%d, %d, 225) result" % (world, G, steps)},
+        "gathered_output": gathered,
         "forward_tflops": round(fwd_flop * steps / dt / 1e12, 1),
-        "forward_mfma_frac": round(fwd_flop * steps / dt / 1e12 / PEAK_BF16_TFLOPS, 4),
-        "parity_full_rows": parity, "kernels": kern}))
+        "forward_mfma_frac": round(fwd_flop * steps / dt / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+        "parity_full_rows": parity, "kernels": kern}
+    if dry:
+        out_line["dry_run"] = "gloo, ranks sharing devices: control-flow check of the N > 1 path, not a measurement"
+    print(json.dumps(out_line))
 
 
-def run_scaled(args, device):
+def run_scaled(args, device, world=1, rank=0, dry=False):
     """BASELINE.json configs[4]: full-depth scaled FACT (d=1536, 12 heads, ff=6144, 2+2 encoder and 24
-    cross-modal layers, seq 480/960 -> n=1440: tiled attention kernels), train steps at --batch sequences."""
+    cross-modal layers, seq 480/960 -> n=1440: streaming attention kernels), train steps at --batch sequences per GPU
+    through the same data-parallel step as --mode train (bf16 gradient buckets overlapped with backward; 1.59 GB per
+    step at N > 1)."""
     from mint_amd import configs, model_builder
-    from mint_amd.trainer import Adam, SingleTaskTrainer
+    from mint_amd.trainer import Adam
     B = args.batch or 8
     mm = configs.fact_config(motion=(480, 225, 1536, 2, 12, 6144), audio=(960, 35, 1536, 2, 12, 6144),
                              cross=(1536, 24, 12, 6144))
     model = model_builder.build(mm, True)
-    gen = torch.Generator().manual_seed(9)
+    gen = torch.Generator().manual_seed(9 + rank)
     batch = {"motion_input": torch.randn(B, 480, 225, generator=gen).to(device),
              "audio_input": torch.randn(B, 960, 35, generator=gen).to(device),
              "target": torch.randn(B, TARGET_LEN, 225, generator=gen).to(device)}
     model.build(B, 225, 35)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        model.set_option(k, int(v))
+    if world > 1 and not args.dp_aux_stream:
+        model.set_option("aux_stream", 0)
+    apply_opts(model, args)
     nparams = sum(int(v.numel()) for v in model.trainable_variables)
-
-    class Repeat:
-        def __iter__(self):
-            return self
-
-        def __next__(self):
-            return batch
-    tr = SingleTaskTrainer(Repeat(), "target", model, optimizer=Adam(1e-4))
-    it = iter(Repeat())
-    for _ in range(args.warmup):
-        tr.train_step(it)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = tr.train_step(it)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
+    tr, it = make_trainer(model, batch, Adam(1e-4), args, world)
+    dt, loss = timed_train_steps(tr, it, args, world, device, dry)
+    dt /= args.steps
     kern = None
     if args.profile_steps > 0:
         psteps = min(args.profile_steps, 2)
@@ -370,25 +452,38 @@ def run_scaled(args, device):
         for _ in range(psteps):
             tr.train_step(it)
         kern = class_table(model, psteps)
+    comm = comm_record(tr, it, args, world)
     parity = None
-    if args.parity:
+    if args.parity and rank == 0 and world == 1:
         parity = scaled_parity(model, device)
+    if world > 1:
+        sync_all(world)
+    if rank != 0:
+        return
     d, ff, n = 1536, 6144, 1440
     lin = lambda tokens, layers: 2.0 * tokens * layers * (4 * d * d + 2 * d * ff)
     attn = lambda tok, layers: 4.0 * tok * tok * d * layers
     fwd = (lin(480, 2) + lin(960, 2) + lin(n, 24) + attn(480, 2) + attn(960, 2) + attn(n, 24)
            + 2.0 * (480 * 225 + 960 * 35 + n * 225) * d)
-    step_flop = 3.0 * fwd * B
-    print(json.dumps({
+    step_flop = 3.0 * fwd * B * world
+    out_line = {
         "metric": "motion frames/sec (train step) scaled FACT d=1536 x 24 cross layers",
-        "value": round(B * 480 / dt, 1), "unit": "motion frames/sec", "n_gpus": 1, "steps": args.steps,
+        "value": round(world * B * 480 / dt, 1), "unit": "motion frames/sec", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "scaled FACT train step (BASELINE.json configs[4], per-GPU share)", "per_gpu_batch": B,
-                   "motion_seq": 480, "audio_seq": 960, "hidden": d, "cross_layers": 24, "params": nparams},
+        "config": {"workload": "scaled FACT train step (BASELINE.json configs[4])", "global_batch": world * B,
+                   "per_gpu_batch": B, "motion_seq": 480, "audio_seq": 960, "hidden": d, "cross_layers": 24,
+                   "params": nparams, "parallelism": "dp%d" % world,
+                   "grad_allreduce": ("none (single replica)" if world == 1 else
+                                      "%s buckets on a communication stream, overlapped with backward" % args.grad_buckets)},
         "step_tflops": round(step_flop / dt / 1e12, 1),
-        "step_mfma_frac": round(step_flop / dt / 1e12 / PEAK_BF16_TFLOPS, 4), "final_loss": round(float(loss), 5),
-        "parity_vs_oracle": parity, "kernels": kern}))
+        "step_mfma_frac": round(step_flop / dt / 1e12 / (PEAK_BF16_TFLOPS * world), 4), "final_loss": round(loss, 5),
+        "parity_vs_oracle": parity, "kernels": kern}
+    if comm is not None:
+        out_line["comm"] = comm
+    if dry:
+        out_line["dry_run"] = "gloo, ranks sharing devices: control-flow check of the N > 1 path, not a measurement"
+    print(json.dumps(out_line))
 
 
 def scaled_parity(model, device):
@@ -445,13 +540,15 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    if args.mode == "ar":
-        return run_ar(args, device)
-    if args.mode == "scaled":
-        return run_scaled(args, device)
+    if args.mode in ("ar", "scaled"):
+        (run_ar if args.mode == "ar" else run_scaled)(args, device, world, rank, dry)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from mint_amd import configs, model_builder
     from mint_amd.learning_schedules import create_learning_rate
-    from mint_amd.trainer import Adam, SingleTaskTrainer
+    from mint_amd.trainer import Adam
 
     pipe = configs.fact_v5_deeper_t10_cm12()
     model = model_builder.build(pipe.multi_modal_model, True)
@@ -464,42 +561,10 @@ def main():
     model.set_option("side_stream", args.side_stream)
     if world > 1 and not args.dp_aux_stream:
         model.set_option("aux_stream", 0)
-    for kv in args.opt:
-        k, v = kv.split("=")
-        model.set_option(k, int(v))
+    apply_opts(model, args)
     opt = Adam(create_learning_rate(pipe.train_config.learning_rate))
-
-    class Repeat:
-        def __iter__(self):
-            return self
-
-        def __next__(self):
-            return batch
-
-    trainer = SingleTaskTrainer(Repeat(), "target", model, optimizer=opt, fuse_optimizer=bool(args.fuse_optimizer),
-                                bf16_grad_buckets=(world > 1 and args.grad_buckets == "bf16"),
-                                overlap_grad_allreduce=(True if world > 1 else None))
-    it = iter(Repeat())
-
-    def sync():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    trainer.train_loop_begin()
-    for _ in range(args.warmup):
-        trainer.train_step(it)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.train_step(it)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    final_loss = float(loss)
+    trainer, it = make_trainer(model, batch, opt, args, world)
+    dt, final_loss = timed_train_steps(trainer, it, args, world, device, dry)
 
     if args.breakdown and rank == 0:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -522,14 +587,7 @@ def main():
             file=sys.stderr)
 
     rows, ksum_ms = kernel_table(model, lambda: trainer.train_step(it), max(1, args.profile_steps))
-    comm = None
-    if world > 1 and getattr(trainer, "_reducer", None) is not None:
-        # per-bucket all-reduce time and exposed communication (diagnosis of a bad scaling record; after the timed region)
-        trainer._reducer.profile = True
-        for _ in range(max(1, args.profile_steps)):
-            trainer.train_step(it)
-        comm = trainer._reducer.comm_report()
-        trainer._reducer.profile = False
+    comm = comm_record(trainer, it, args, world)
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         frames_per_s = world * B * 120 / (dt / args.steps)

@@ -92,6 +92,12 @@ int fact_refresh_weights(FactHandle* h, void* stream);
 int fact_forward(FactHandle* h, const float* motion, const float* audio, int B, float* out,
                  void* stream);
 
+/* Replaces FACTModel.loss / compute_motion_generation_loss (fact_model.py:134-148; argument order (target, pred) as
+ * the reference calls it, single_task_trainer.py:157): *loss_out (device float[1]) = mean((target - pred[:, :T])^2) with
+ * target (B, T, D) and pred (B, n, D), T <= n.  The training step does not call it: fact_forward_backward fuses the
+ * same kernel with the gradient of the loss. */
+int fact_loss(const float* target, const float* pred, int B, int n, int T, int D, float* loss_out, void* stream);
+
 /* Replaces the tape section of train_fn (single_task_trainer.py:141-178): forward, loss
  * (fact_model.py:143-148; target (B, T, out_dim)), backward.  Gradients of (loss * loss_scale)
  * are ACCUMULATED into the grad arena (loss_scale = 1/num_replicas, single_task_trainer.py:158).
@@ -129,15 +135,6 @@ int fact_num_buckets(FactHandle* h, int* n);
 int fact_cast_f32_bf16(const float* src, void* dst_bf16, size_t n, void* stream);
 int fact_cast_bf16_f32(const void* src_bf16, float* dst, size_t n, void* stream);
 
-/* In-step kernel-class timing.  fact_kprof(h, 1) arms it (and clears earlier records): every instrumented launch
- * site of the following forward / backward calls is bracketed by HIP events recorded on the stream it launches
- * on, with all the stream overlap of a normal step.  fact_kprof_read synchronises the device and returns, per
- * kernel class, the number of launches, the summed event time (ms), the algorithmic FLOPs and bytes.  Measurement
- * aid of bench.py, not part of the reference surface. */
-int fact_kprof(FactHandle* h, int on);
-int fact_kprof_dump(FactHandle* h, const char* path); /* CSV timeline: class, stream, start_us, end_us */
-int fact_kprof_read(FactHandle* h, int max_classes, int* n_classes, const char** names, double* launches,
-                    double* total_ms, double* flops, double* bytes);
 int fact_get_step(FactHandle* h, int64_t* step);
 int fact_set_step(FactHandle* h, int64_t step);
 
@@ -161,87 +158,28 @@ int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, i
 typedef void (*fact_grad_cb)(void* user, int bucket, size_t offset_floats, size_t count_floats);
 int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* comm_stream);
 
-/* Engine knobs (default 1 unless stated; the 0 settings are the reference paths the tests compare against):
- *   "wgrad_tr"       1 = wgrad GEMM builds its fragments with the LDS transpose read, 0 = explicit transposes
- *   "wgrad_slab"     1 = split-K partials as plain stores + a streaming reduce, 0 = fp32 atomics
- *   "side_stream"    1 = wgrad batches / the audio encoder run on the handle's second stream, 0 = one stream
- *   "fuse_adam_cast" 1 = Adam writes the bf16 weight shadows itself, 0 = Adam, then a cast/transpose pass
- *   "sr_rows"        1 = the last cross-modal layer + head run on the rows that are kept: the B*T supervised rows of a
- *                        train step (fact_model.py:143-148) and the one generated row per sequence of fact_infer_ar
- *                        (fact_model.py:128), whose GEMMs of <= 512 rows are then cut along K (fp32 atomics: equal up to
- *                        summation order, not bit for bit from run to run); 0 = every layer on all rows.  fact_forward is
- *                        never affected.
+/* Engine options (production surface; unknown keys return an error - the kernel-selection / scheduling A/B switches and
+ * the timing-only ablation mask of the test and bench builds live behind fact_debug_set_option in fact_hip_debug.h and
+ * are NOT accepted here):
+ *   "sr_rows"        (default 1) 1 = the last cross-modal layer + head run on the rows that are kept: the B*T supervised
+ *                        rows of a train step (fact_model.py:143-148) and the one generated row per sequence of
+ *                        fact_infer_ar (fact_model.py:128), whose GEMMs of <= 512 rows are then cut along K (fp32 atomics:
+ *                        equal up to summation order, not bit for bit from run to run); 0 = every layer on all rows.
+ *                        fact_forward is never affected.
  *   "grad_overwrite" (default 0) 1 = fact_forward_backward WRITES the gradient of every transformer-layer Dense kernel
  *                        (plain stores of the whole-K grouped wgrad launch) instead of adding to it, and the optimizer
  *                        pass leaves those ranges as they are instead of zeroing them: 32 instead of 36 bytes per
  *                        parameter in the optimizer pass and no read-modify-write in the wgrad epilogue.  For hosts that
  *                        call fact_forward_backward exactly once per optimizer step (mint_amd/trainer.py sets it; the
  *                        reference's train_fn has no gradient accumulation either, single_task_trainer.py:141-196);
- *                        with 0 gradients accumulate across calls until fact_adam_step zeroes them.
- *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "bwd_splitk", "aux_stream", "adam_hold", "tn_loop",
- *   "attn_variant", "adam_variant", "big_impl", "ln_fuse", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on 64-deep ring slots; default 3), "lite_stream": scheduling / kernel-selection knobs of the A/B runs
- *   documented in DESIGN.md sections 3 and 6; results are unchanged by them.  "skip": timing-only ablation mask
- *   (DESIGN 6), results are WRONG while it is set.
- * Unknown keys return an error. */
+ *                        with 0 gradients accumulate across calls until fact_adam_step zeroes them.  Per handle: a new
+ *                        handle starts at 0 with a zeroed gradient arena (caller-provided arenas included), and setting
+ *                        it back to 0 clears the ranges that were being overwritten, so accumulation never starts on
+ *                        a stale gradient.
+ *   "side_stream"    (default 1) 1 = the weight-gradient batches / the audio encoder run on the handle's second stream
+ *   "aux_stream"     (default 1) 1 = the motion encoder's backward chain runs on the handle's third stream; hosts that
+ *                        add a communication stream (data parallelism) set 0 to stay within the hardware queues */
 int fact_set_option(FactHandle* h, const char* key, int value);
-
-/* ---- single-op entry points (used by the parity tests; same kernels as the model path) ---- */
-/* C = A(MxK) * B^T(NxK) ; epi selects the fused epilogue (see gemm.h); bf16 operands. */
-int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
-                    void* out0, int ldo0, void* out1, int ldo1, const float* bias, const float* pos,
-                    int seq, const float* resid, int ldr, const void* pre, int ldp, void* stream);
-/* C(MoxNo) += A^T B with A [K][Mo], B [K][No] bf16 (wgrad form), f32 atomic accumulate. */
-int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int No, int K,
-                    float* out, int ldo, int splitk, int use_tr, void* scratch, void* stream);
-/* Grouped whole-K weight-gradient GEMM (one launch for the 1..4 wgrads of a transformer layer, 160x256 tiles,
- * no split-K): out_i[Mo_i][No_i] += A_i^T B_i with A_i bf16 [K][lda_i], B_i bf16 [K][ldb_i]; trans[i] = 1
- * stores out_i as [No_i][Mo_i].  K % 32 == 0, Mo / No / ldo % 4 == 0.  Replaces the tape's Dense-kernel
- * gradients (single_task_trainer.py:175-178 through base_models.py:51-53,68-69). */
-int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
-                          float* const* out, const int* ldo, const int* Mo, const int* No, const int* trans, int K,
-                          void* stream);
-int fact_op_ln_fwd(const float* x, const float* gamma, const float* beta, void* h, float* mean,
-                   float* rstd, int M, int C, float eps, void* stream);
-int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
-                   const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
-                   float* dbeta, float* dbias_prev, int M, int C, void* stream);
-/* qkv: bf16 [B*n][3*hid] in (qkv h d) column order -> out bf16 [B*n][hid]; if dout != NULL also
- * runs the backward and writes dqkv bf16 [B*n][3*hid].  `scratch` >= fact_op_attention_scratch(). */
-size_t fact_op_attention_scratch(int B, int H, int n, int dh);
-int fact_op_attention(const void* qkv, int B, int H, int n, int dh, float scale, void* out,
-                      const void* dout, void* dqkv, void* scratch, void* stream);
-int fact_op_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, float b1, float b2,
-                 float eps, void* stream);
-int fact_op_mse(const float* pred, const float* target, float* loss, void* dpred, int B, int n, int T,
-                int D, int ldp, float gscale, void* stream);
-/* MFMA / LDS-transpose-read layout probes (diagnostics). a_regs/b_regs: f32[64*8] per-lane operand
- * registers (rounded to bf16), d_regs: f32[64*4].  lds_vals: n<=4096 values placed in LDS as bf16,
- * byte_addrs: int[64] per-lane LDS byte address, out: f32[64*4] = what each lane received. */
-int fact_probe_mfma(const float* a_regs, const float* b_regs, float* d_regs, void* stream);
-int fact_probe_tr(const float* lds_vals, int n, const int* byte_addrs, float* out, void* stream);
-/* Test knob: route every GEMM through the register-staged generic kernels (process-global). */
-int fact_debug_force_generic_gemm(int on);
-/* Test knob: 1 = use the tiled (streaming) attention kernels even when the LDS-resident ones fit. */
-int fact_debug_attn_force_tiled(int on);
-/* Test/bench knob: attention kernel family. 1 (default) = one workgroup per (batch, head) with K/V resident in
- * LDS when they fit, tiled kernels otherwise; 2 = streaming 4-wave kernels (128-row blocks, LDS-DMA ring). */
-int fact_debug_attn_variant(int v);
-int fact_debug_attn_variant_get(void); /* the current family (tests restore it) */
-/* Bench only: device buffer of u64[B*H][waves][8] that receives per-wave s_memtime stamps of the LDS-resident
- * forward attention kernel (null = off). */
-int fact_debug_attn_timestamps(void* buf);
-/* bench only: `nwg` one-per-CU workgroups that spin for ~`micros` microseconds on `stream` (CU-availability probe) */
-int fact_debug_cu_hog(int nwg, int micros, void* stream);
-/* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 6 / 7 = big-tile 288x256 / 256x256). */
-int fact_debug_gemm_splitk_max(int v); /* in-kernel split-K slices of the N = 800 GEMMs (1 = off, default 4) */
-int fact_debug_gemm_tn_cfg(int v); /* grouped wgrad tile: 0 = 160x256, 1 = 160x384 */
-int fact_debug_gemm_big_impl(int v); /* 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel */
-int fact_debug_gemm_nt_variant(int v);
-/* Test/bench knob: NT GEMM tile band height (tile order inside an XCD; 1 = row-major, default 8). */
-int fact_debug_gemm_nt_band(int band);
-/* Test/bench knob: LayerNorm-backward rows per workgroup (multiple of 4, >= 8); use_ws != 0 makes
- * fact_op_ln_bwd use the engine's partial-sum workspace path instead of atomics. */
-int fact_debug_ln_bwd(int rows_per_block, int use_ws);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,102 @@
+/* fact_hip_debug.h - test / bench surface of libfact_hip.so.  NOT part of the drop-in boundary (include/fact_hip.h is):
+ * single-op entry points the parity tests drive the kernels through, layout probes, the in-step kernel-class recorder of
+ * bench.py, process-wide kernel-selection switches and the string-keyed A/B options of the engine - one of which ("skip")
+ * produces wrong results by design.  A host that binds the engine for training or inference needs none of this. */
+#ifndef FACT_HIP_DEBUG_H_
+#define FACT_HIP_DEBUG_H_
+
+#include "fact_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* In-step kernel-class timing.  fact_kprof(h, 1) arms it (and clears earlier records): every instrumented launch
+ * site of the following forward / backward calls is bracketed by HIP events recorded on the stream it launches
+ * on, with all the stream overlap of a normal step.  fact_kprof_read synchronises the device and returns, per
+ * kernel class, the number of launches, the summed event time (ms), the algorithmic FLOPs and bytes.  Measurement
+ * aid of bench.py, not part of the reference surface. */
+int fact_kprof(FactHandle* h, int on);
+int fact_kprof_dump(FactHandle* h, const char* path); /* CSV timeline: class, stream, start_us, end_us */
+int fact_kprof_read(FactHandle* h, int max_classes, int* n_classes, const char** names, double* launches,
+                    double* total_ms, double* flops, double* bytes);
+/* The kernels behind class `cls` (index into fact_kprof_read's arrays) as the recorder saw them launched: text lines
+ * "count\\tgrid\\tblock\\tlds_bytes\\tworkgroups_per_cu\\tkernel name" (most frequent first; the name is what rocprofv3 prints for
+ * the same dispatch, workgroups_per_cu the runtime's occupancy answer for that launch shape) - bench.py names the symbol
+ * that really ran and the CUs its grid can hold from this instead of from a hand-kept table. */
+int fact_kprof_kernels(FactHandle* h, int cls, char* buf, int cap);
+
+/* Test / bench knobs of one handle (several are process-wide, as noted).  Results are unchanged by every key except
+ * "skip"; the production keys of fact_set_option are accepted too.
+ *   "wgrad_tr"       1 = wgrad GEMM builds its fragments with the LDS transpose read, 0 = explicit transposes
+ *   "wgrad_slab"     1 = split-K partials as plain stores + a streaming reduce, 0 = fp32 atomics
+ *   "fuse_adam_cast" 1 = Adam writes the bf16 weight shadows itself, 0 = Adam, then a cast/transpose pass
+ *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "bwd_splitk", "adam_hold", "ln_fuse", "lite_stream", "keep_pre":
+ *                    scheduling / fusion switches of the A/B runs documented in DESIGN.md sections 3 and 6
+ *   "tn_loop", "attn_variant", "adam_variant", "big_impl", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on
+ *                    64-deep ring slots; default 3): PROCESS-WIDE kernel selection
+ *   "skip":          TIMING-ONLY ablation mask: results are WRONG while it is set */
+int fact_debug_set_option(FactHandle* h, const char* key, int value);
+
+/* ---- single-op entry points (used by the parity tests; same kernels as the model path) ---- */
+/* C = A(MxK) * B^T(NxK) ; epi selects the fused epilogue (see gemm.h); bf16 operands. */
+int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int M, int N, int K,
+                    void* out0, int ldo0, void* out1, int ldo1, const float* bias, const float* pos,
+                    int seq, const float* resid, int ldr, const void* pre, int ldp, void* stream);
+/* C(MoxNo) += A^T B with A [K][Mo], B [K][No] bf16 (wgrad form), f32 atomic accumulate. */
+int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int No, int K,
+                    float* out, int ldo, int splitk, int use_tr, void* scratch, void* stream);
+/* Grouped whole-K weight-gradient GEMM (one launch for the 1..4 wgrads of a transformer layer, 160x256 tiles,
+ * no split-K): out_i[Mo_i][No_i] += A_i^T B_i with A_i bf16 [K][lda_i], B_i bf16 [K][ldb_i]; trans[i] = 1
+ * stores out_i as [No_i][Mo_i].  K % 32 == 0, Mo / No / ldo % 4 == 0.  Replaces the tape's Dense-kernel
+ * gradients (single_task_trainer.py:175-178 through base_models.py:51-53,68-69). */
+int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                          float* const* out, const int* ldo, const int* Mo, const int* No, const int* trans, int K,
+                          void* stream);
+int fact_op_ln_fwd(const float* x, const float* gamma, const float* beta, void* h, float* mean,
+                   float* rstd, int M, int C, float eps, void* stream);
+int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
+                   const float* gamma, const float* dres, float* dx, void* dx_bf16, float* dgamma,
+                   float* dbeta, float* dbias_prev, int M, int C, void* stream);
+/* qkv: bf16 [B*n][3*hid] in (qkv h d) column order -> out bf16 [B*n][hid]; if dout != NULL also
+ * runs the backward and writes dqkv bf16 [B*n][3*hid].  `scratch` >= fact_op_attention_scratch(). */
+size_t fact_op_attention_scratch(int B, int H, int n, int dh);
+int fact_op_attention(const void* qkv, int B, int H, int n, int dh, float scale, void* out,
+                      const void* dout, void* dqkv, void* scratch, void* stream);
+int fact_op_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, float b1, float b2,
+                 float eps, void* stream);
+int fact_op_mse(const float* pred, const float* target, float* loss, void* dpred, int B, int n, int T,
+                int D, int ldp, float gscale, void* stream);
+/* MFMA / LDS-transpose-read layout probes (diagnostics). a_regs/b_regs: f32[64*8] per-lane operand
+ * registers (rounded to bf16), d_regs: f32[64*4].  lds_vals: n<=4096 values placed in LDS as bf16,
+ * byte_addrs: int[64] per-lane LDS byte address, out: f32[64*4] = what each lane received. */
+int fact_probe_mfma(const float* a_regs, const float* b_regs, float* d_regs, void* stream);
+int fact_probe_tr(const float* lds_vals, int n, const int* byte_addrs, float* out, void* stream);
+/* Test knob: route every GEMM through the register-staged generic kernels (process-global). */
+int fact_debug_force_generic_gemm(int on);
+/* Test knob: 1 = use the tiled (streaming) attention kernels even when the LDS-resident ones fit. */
+int fact_debug_attn_force_tiled(int on);
+/* Test/bench knob: attention kernel family. 1 (default) = one workgroup per (batch, head) with K/V resident in
+ * LDS when they fit, tiled kernels otherwise; 2 = streaming 4-wave kernels (128-row blocks, LDS-DMA ring). */
+int fact_debug_attn_variant(int v);
+int fact_debug_attn_variant_get(void); /* the current family (tests restore it) */
+/* Bench only: device buffer of u64[B*H][waves][8] that receives per-wave s_memtime stamps of the LDS-resident
+ * forward attention kernel (null = off). */
+int fact_debug_attn_timestamps(void* buf);
+/* bench only: `nwg` one-per-CU workgroups that spin for ~`micros` microseconds on `stream` (CU-availability probe) */
+int fact_debug_cu_hog(int nwg, int micros, void* stream);
+/* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 6 / 7 = big-tile 288x256 / 256x256). */
+int fact_debug_gemm_splitk_max(int v); /* in-kernel split-K slices of the N = 800 GEMMs (1 = off, default 4) */
+int fact_debug_gemm_tn_cfg(int v); /* grouped wgrad tile: 0 = 160x256, 1 = 160x384 */
+int fact_debug_gemm_big_impl(int v); /* 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel */
+int fact_debug_gemm_nt_variant(int v);
+/* Test/bench knob: NT GEMM tile band height (tile order inside an XCD; 1 = row-major, default 8). */
+int fact_debug_gemm_nt_band(int band);
+/* Test/bench knob: LayerNorm-backward rows per workgroup (multiple of 4, >= 8); use_ws != 0 makes
+ * fact_op_ln_bwd use the engine's partial-sum workspace path instead of atomics. */
+int fact_debug_ln_bwd(int rows_per_block, int use_ws);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FACT_HIP_DEBUG_H_ */

@@ -1,4 +1,5 @@
-"""ctypes binding of libfact_hip.so (the C ABI declared in include/fact_hip.h).
+"""ctypes binding of libfact_hip.so: the drop-in C ABI declared in include/fact_hip.h plus the test / bench surface of
+include/fact_hip_debug.h (DEBUG_SYMBOLS below: single-op entry points, probes, the kernel-class recorder, A/B knobs).
 
 There is deliberately no CPU fallback: if the HIP library is missing or does not load, importing
 this module's `lib()` raises.  The oracle under /oracle is test infrastructure and is never
@@ -40,7 +41,7 @@ class FactArenas(C.Structure):
 # fact_grad_cb: void (*)(void* user, int bucket, size_t offset_floats, size_t count_floats)
 GRAD_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t)
 
-# name -> (restype, argtypes); kept in sync with include/fact_hip.h (tests check every symbol)
+# name -> (restype, argtypes); kept in sync with include/fact_hip.h + fact_hip_debug.h (tests check every symbol)
 _vp, _i, _f, _sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
 SIGNATURES = {
     "fact_abi_version": (_i, []),
@@ -60,10 +61,13 @@ SIGNATURES = {
     "fact_adam_bucket_bf16": (_i, [_vp, _i, _vp, _vp]),
     "fact_adam_cancel": (_i, [_vp]),
     "fact_num_buckets": (_i, [_vp, C.POINTER(_i)]),
+    "fact_loss": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "fact_kprof": (_i, [_vp, _i]),
     "fact_kprof_dump": (_i, [_vp, C.c_char_p]),
     "fact_kprof_read": (_i, [_vp, _i, C.POINTER(_i), C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                              C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "fact_kprof_kernels": (_i, [_vp, _i, C.c_char_p, _i]),
+    "fact_debug_set_option": (_i, [_vp, C.c_char_p, _i]),
     "fact_get_step": (_i, [_vp, C.POINTER(C.c_int64)]),
     "fact_set_step": (_i, [_vp, C.c_int64]),
     "fact_infer_ar": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(_i), _vp]),
@@ -97,6 +101,11 @@ SIGNATURES = {
     "fact_debug_attn_timestamps": (_i, [_vp]),
     "fact_debug_cu_hog": (_i, [_i, _i, _vp]),
 }
+
+# declared in include/fact_hip_debug.h (everything else: include/fact_hip.h, the drop-in boundary)
+DEBUG_SYMBOLS = frozenset(n for n in SIGNATURES if n.startswith(("fact_debug_", "fact_op_", "fact_probe_", "fact_kprof")))
+# keys fact_set_option accepts; every other engine knob goes through fact_debug_set_option
+PUBLIC_OPTIONS = ("sr_rows", "grad_overwrite", "side_stream", "aux_stream")
 
 _LIB = None
 

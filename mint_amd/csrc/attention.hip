@@ -1882,7 +1882,7 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
     AttnParams q = p;
     if (!bwd_is_resident<DH>(p.n)) q.nq = 0;
     const int nqv = (q.nq > 0 && q.nq < q.n) ? q.nq : q.n;
-    hipLaunchKernelGGL(attn_fwd_st_kernel<DH>, dim3((nqv + 127) / 128, q.B * q.H), dim3(256), lds, s, q);
+    FACT_LAUNCH(attn_fwd_st_kernel<DH>, dim3((nqv + 127) / 128, q.B * q.H), dim3(256), lds, s, q);
     return 0;
   }
   const size_t lds = res_lds_bytes<DH>(p.n, 0);
@@ -1892,11 +1892,11 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
     const int nw = ((p.n + 31) & ~31) / 32;
     AttnParams q = p;
     if (!bwd_is_resident<DH>(p.n)) q.nq = 0;  // variant 4: the streaming backward reads every row's log-sum-exp
-    hipLaunchKernelGGL(attn_fwd_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds, s, q);
+    FACT_LAUNCH(attn_fwd_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds, s, q);
     return 0;
   }
   dim3 grid((p.n + 127) / 128, p.B * p.H);
-  hipLaunchKernelGGL(attn_fwd_kernel<DH>, grid, dim3(256), 0, s, p);
+  FACT_LAUNCH(attn_fwd_kernel<DH>, grid, dim3(256), 0, s, p);
   return 0;
 }
 template <int DH>
@@ -1907,14 +1907,14 @@ int bwd_t(const AttnParams& p, hipStream_t s) {
     if (int rc = allow_lds_bytes(attn_bwd_dq_st_kernel<DH>, &attr1, lds1)) return rc;
     if (int rc = allow_lds_bytes(attn_bwd_dkdv_st_kernel<DH>, &attr2, lds2)) return rc;
     const dim3 grid((p.n + 127) / 128, p.B * p.H);
-    hipLaunchKernelGGL(attn_bwd_dq_st_kernel<DH>, grid, dim3(256), lds1, s, p);
-    hipLaunchKernelGGL(attn_bwd_dkdv_st_kernel<DH>, grid, dim3(256), lds2, s, p);
+    FACT_LAUNCH(attn_bwd_dq_st_kernel<DH>, grid, dim3(256), lds1, s, p);
+    FACT_LAUNCH(attn_bwd_dkdv_st_kernel<DH>, grid, dim3(256), lds2, s, p);
     return 0;
   }
   const int total = p.B * p.H * p.NP;
   const size_t lds1 = res_lds_bytes<DH>(p.n, 1), lds2 = res_lds_bytes<DH>(p.n, 2);
   // the LDS-resident dQ kernel computes D = rowsum(dO o O) itself; only the tiled path needs the pass
-  if (!lds1) hipLaunchKernelGGL(attn_bwd_prep_kernel<DH>, dim3((total + 255) / 256), dim3(256), 0, s, p);
+  if (!lds1) FACT_LAUNCH(attn_bwd_prep_kernel<DH>, dim3((total + 255) / 256), dim3(256), 0, s, p);
   const int nw = ((p.n + 31) & ~31) / 32;
   dim3 grid((p.n + 127) / 128, p.B * p.H);
   if constexpr (DH <= 96) {
@@ -1922,36 +1922,36 @@ int bwd_t(const AttnParams& p, hipStream_t s) {
     if (lds1 && r2 && pk) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dq_r2_kernel<DH, 1>, &attr)) return rc;
-      hipLaunchKernelGGL((attn_bwd_dq_r2_kernel<DH, 1>), dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
+      FACT_LAUNCH((attn_bwd_dq_r2_kernel<DH, 1>), dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
     } else if (lds1 && r2) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dq_r2_kernel<DH, 0>, &attr)) return rc;
-      hipLaunchKernelGGL((attn_bwd_dq_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
+      FACT_LAUNCH((attn_bwd_dq_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
     } else if (lds1) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dq_res_kernel<DH>, &attr)) return rc;
-      hipLaunchKernelGGL(attn_bwd_dq_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
+      FACT_LAUNCH(attn_bwd_dq_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
     } else {
-      hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
+      FACT_LAUNCH(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
     }
     if (lds2 && r2 && pk) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 1>, &attr)) return rc;
-      hipLaunchKernelGGL((attn_bwd_dkdv_r2_kernel<DH, 1>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
+      FACT_LAUNCH((attn_bwd_dkdv_r2_kernel<DH, 1>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
     } else if (lds2 && r2) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 0>, &attr)) return rc;
-      hipLaunchKernelGGL((attn_bwd_dkdv_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
+      FACT_LAUNCH((attn_bwd_dkdv_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
     } else if (lds2) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dkdv_res_kernel<DH>, &attr)) return rc;
-      hipLaunchKernelGGL(attn_bwd_dkdv_res_kernel<DH>, dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
+      FACT_LAUNCH(attn_bwd_dkdv_res_kernel<DH>, dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
     } else {
-      hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
+      FACT_LAUNCH(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
     }
   } else {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
+    FACT_LAUNCH(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
+    FACT_LAUNCH(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
   }
   return 0;
 }

@@ -66,6 +66,18 @@ DEVINL float gelu_tanh_grad(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
 
+// Every kernel launch of the library goes through FACT_LAUNCH.  While the in-step kernel-class recorder is armed
+// (fact_kprof, engine.hip) the launch is also noted - host function, grid, block, dynamic LDS - so that the bench line can
+// name the kernel symbol that really ran and the CUs its grid can hold, instead of a hand-kept table.  One predictable
+// branch otherwise.
+extern bool g_fact_note_on;
+void fact_note_launch(const void* host_fn, dim3 grid, dim3 block, size_t lds_bytes);
+#define FACT_LAUNCH(kernel, grid, block, lds, stream, ...)                                                    \
+  do {                                                                                                          \
+    if (g_fact_note_on) fact_note_launch(reinterpret_cast<const void*>(kernel), (grid), (block), (size_t)(lds)); \
+    hipLaunchKernelGGL(kernel, (grid), (block), (lds), (stream), __VA_ARGS__);                                  \
+  } while (0)
+
 #define HIP_CHECK_RET(expr)                                  \
   do {                                                       \
     hipError_t _e = (expr);                                  \

@@ -12,6 +12,7 @@
 //   activations: residual stream fp32 [B*n][d]; GEMM operands bf16; per-head q/k/v/dO in both
 //     token-major [B*H][NP][DHP] and head-dim-major [B*H][DH][NP] forms (attention.h).
 #include "../../include/fact_hip.h"
+#include "../../include/fact_hip_debug.h"
 #include "attention.h"
 #include "gemm.h"
 #include "rowops.h"
@@ -21,6 +22,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cxxabi.h>
 #include <string>
 #include <vector>
 
@@ -178,9 +180,14 @@ const char* const kKClassName[KP_N] = {
     "ln_fwd", "qkv_gemm+heads", "attention_fwd", "out_proj+resid", "ffn1+gelu", "ffn2+resid", "gelu'_dgrad",
     "ffn1_dgrad", "ln_bwd_dx", "out_proj_dgrad+heads", "attention_bwd", "qkv_dgrad", "wgrad_group",
     "bias/ln_param_grads", "adam+shadows"};
+struct KNote {  // one kernel launch seen by FACT_LAUNCH while the recorder is armed
+  const void* fn;
+  unsigned grid, block;
+  size_t lds;
+};
 struct KProf {
   bool on = false;
-  struct Rec { int cls; int launches; int sid; double flops; double bytes; hipEvent_t a, b; };
+  struct Rec { int cls; int launches; int sid; double flops; double bytes; hipEvent_t a, b; std::vector<KNote> notes; };
   std::vector<Rec> recs;
   std::vector<hipEvent_t> pool;
   size_t used = 0;
@@ -273,7 +280,10 @@ struct FactHandle {
   int ln_fuse = 1;            // skinny-M forward GEMMs with a residual add: the LayerNorm that follows runs inside their
                               // epilogue pass (one launch less per sub-block; batch-1 AR sampler, supervised-rows layer)
   bool keep_pre = true;       // forward stores the dense_1 pre-activations (backward's GELU' reads them); inference entry
-                              // points clear it for their call: 2 bytes x ff per token and layer less to write
+                              // points clear it for their call: 2 bytes x ff per token and layer less to write.  Backward
+                              // never consumes activations of fact_forward / fact_infer_ar: fact_forward_backward always
+                              // re-runs its own forward (there is no split forward / backward entry point)
+  bool keep_pre_infer = false;  // what the inference entry points set keep_pre to (read FACT_KEEP_PRE once, at fact_create)
   int adam_hold = 1;          // in-backward optimizer: hold the head + cross buckets until the last is final
   // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
   fact_grad_cb cb = nullptr;
@@ -282,6 +292,14 @@ struct FactHandle {
   int cb_bucket = 0;
 };
 
+namespace {
+
+}  // namespace
+bool g_fact_note_on = false;
+static std::vector<KNote> g_fact_notes;  // launches since the innermost KScope opened (host enqueue is single-threaded)
+void fact_note_launch(const void* host_fn, dim3 grid, dim3 block, size_t lds_bytes) {
+  g_fact_notes.push_back(KNote{host_fn, grid.x * grid.y * grid.z, block.x * block.y * block.z, lds_bytes});
+}
 namespace {
 
 struct KScope {
@@ -298,9 +316,13 @@ struct KScope {
     (void)hipEventRecord(r.a, s);
     idx = h->kp.recs.size();
     h->kp.recs.push_back(r);
+    g_fact_notes.clear();
   }
   ~KScope() {
-    if (idx != (size_t)-1) (void)hipEventRecord(h->kp.recs[idx].b, s);
+    if (idx == (size_t)-1) return;
+    (void)hipEventRecord(h->kp.recs[idx].b, s);
+    h->kp.recs[idx].notes.swap(g_fact_notes);
+    g_fact_notes.clear();
   }
 };
 
@@ -1445,6 +1467,7 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
   init_geo(h, cfg);
   h->max_batch = max_batch;
   h->training = training != 0;
+  h->keep_pre_infer = getenv("FACT_KEEP_PRE") != nullptr;
   build_table(h, &h->table, &h->arena_floats);
   const size_t abytes = h->arena_floats * sizeof(float);
   if (arenas && arenas->params) {
@@ -1456,6 +1479,10 @@ int fact_create(const FactConfig* cfg, int max_batch, int training, const FactAr
       delete h;
       return fail(-1, "training handle needs grads/adam_m/adam_v arenas");
     }
+    // a new handle starts with accumulate semantics (grad_overwrite = 0): whatever an earlier handle left in the
+    // caller's gradient arena - ranges that only ever got plain stores under grad_overwrite included - must not be
+    // added to the first gradient of this one
+    if (h->training) HIPCHK(hipMemset(h->grads, 0, abytes));
   } else {
     h->own_arenas = true;
     HIPCHK(hipMalloc((void**)&h->params, abytes));
@@ -1577,7 +1604,45 @@ int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* com
   return 0;
 }
 
+// Gradient ranges the grouped wgrad launch owns under grad_overwrite (every Dense kernel of a transformer layer): with
+// the option on nobody zeroes them - the next step's plain stores replace them.  Whenever accumulate semantics
+// (re)start on an arena that may hold such values - the option going 1 -> 0, a training handle created on caller
+// arenas - they are cleared, otherwise the next fact_forward_backward would add a fresh gradient to a stale one.
+static int zero_overwritten_grads(FactHandle* h) {
+  if (!h->training || !h->grads) return 0;
+  for (Stack* st : {&h->cross, &h->motion, &h->audio})
+    for (const LayerP& p : st->lp)
+      for (const DenseW* w : {&p.wqkv, &p.wo, &p.w1, &p.w2})
+        HIPCHK(hipMemset(h->grads + w->w.off, 0, w->w.numel() * sizeof(float)));
+  return 0;
+}
+
+/* Production options (include/fact_hip.h). */
 int fact_set_option(FactHandle* h, const char* key, int value) {
+  if (!h || !key) return fail(-1, "null argument");
+  if (!strcmp(key, "grad_overwrite")) {
+    if (h->grad_overwrite && !value) CHK(zero_overwritten_grads(h));
+    h->grad_overwrite = value != 0;
+    return 0;
+  }
+  if (!strcmp(key, "sr_rows")) {  // supervised-rows shortcut of the last cross-modal layer (training step)
+    h->sr_rows = value;
+    return 0;
+  }
+  if (!strcmp(key, "aux_stream")) {
+    h->use_aux = value;
+    return 0;
+  }
+  if (!strcmp(key, "side_stream")) {
+    h->use_side = value;
+    return 0;
+  }
+  return fail(-1, std::string("unknown option ") + key + " (A/B and ablation knobs: fact_debug_set_option, fact_hip_debug.h)");
+}
+
+/* Test / bench knobs (include/fact_hip_debug.h): kernel-selection and scheduling A/B switches, the timing-only ablation
+ * mask.  Not part of the drop-in surface; several are process-wide. */
+int fact_debug_set_option(FactHandle* h, const char* key, int value) {
   if (!h || !key) return fail(-1, "null argument");
   if (!strcmp(key, "fuse_adam_cast")) {
     h->fuse_adam_cast = value;
@@ -1604,11 +1669,7 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     gemm_set_k64(value);
     return 0;
   }
-  if (!strcmp(key, "grad_overwrite")) {
-    h->grad_overwrite = value;
-    return 0;
-  }
-  if (!strcmp(key, "skip")) {
+  if (!strcmp(key, "skip")) {  // TIMING ONLY: results are wrong while it is set
     h->skip = value;
     return 0;
   }
@@ -1624,7 +1685,7 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     gemm_set_big_impl(value);
     return 0;
   }
-  if (!strcmp(key, "attn_variant")) {  // process-wide: 1 LDS-resident / tiled attention kernels (default), 2 streaming
+  if (!strcmp(key, "attn_variant")) {  // process-wide: attention kernel family (attention.h)
     attn_set_variant(value);
     return 0;
   }
@@ -1640,10 +1701,6 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     h->wgrad_defer = value;
     return 0;
   }
-  if (!strcmp(key, "sr_rows")) {  // supervised-rows shortcut of the last cross-modal layer (training step)
-    h->sr_rows = value;
-    return 0;
-  }
   if (!strcmp(key, "bwd_splitk")) {
     h->bwd_splitk = value;
     return 0;
@@ -1656,15 +1713,11 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
     h->wgrad_big = value;
     return 0;
   }
-  if (!strcmp(key, "aux_stream")) {
-    h->use_aux = value;
+  if (!strcmp(key, "keep_pre")) {  // 1 = inference entry points store the dense_1 pre-activations too (A/B of that store)
+    h->keep_pre_infer = value != 0;
     return 0;
   }
-  if (!strcmp(key, "side_stream")) {
-    h->use_side = value;
-    return 0;
-  }
-  return fail(-1, std::string("unknown option ") + key);
+  return fact_set_option(h, key, value);  // the production keys are accepted here too
 }
 
 static int head_forward(FactHandle* h, int B, float* out, hipStream_t s) {
@@ -1684,7 +1737,7 @@ int fact_forward(FactHandle* h, const float* motion, const float* audio, int B, 
   hipStream_t s = (hipStream_t)stream;
   struct InferScope {  // forward only: nobody reads the pre-activations
     FactHandle* h;
-    explicit InferScope(FactHandle* hh) : h(hh) { h->keep_pre = getenv("FACT_KEEP_PRE") != nullptr; }  // env: A/B knob
+    explicit InferScope(FactHandle* hh) : h(hh) { h->keep_pre = h->keep_pre_infer; }  // debug option "keep_pre"
     ~InferScope() { h->keep_pre = true; }
   } infer_scope(h);
   CHK(model_forward_hidden(h, motion, (size_t)h->motion.n * h->motion.feat, audio,
@@ -1882,6 +1935,50 @@ int fact_kprof(FactHandle* h, int on) {
   h->kp.on = on != 0;
   h->kp.recs.clear();
   h->kp.used = 0;
+  g_fact_note_on = h->kp.on;
+  g_fact_notes.clear();
+  return 0;
+}
+
+/* The kernels behind one class of the table, as the recorder saw them launched (FACT_LAUNCH): one text line per distinct
+ * (kernel, grid, block, dynamic LDS), most frequent first:
+ *   count \t grid \t block \t lds_bytes \t workgroups_per_cu \t demangled kernel name
+ * workgroups_per_cu is the runtime's occupancy answer for that launch shape, so min(256, ceil(grid / wgs_per_cu)) is the
+ * number of CUs the launch can hold.  Names are what rocprofv3 prints for the same dispatches. */
+int fact_kprof_kernels(FactHandle* h, int cls, char* buf, int cap) {
+  if (!h || !buf || cap <= 0) return fail(-1, "null argument");
+  if (cls < 0 || cls >= KP_N) return fail(-1, "no such kernel class");
+  struct Agg { KNote n; long count; };
+  std::vector<Agg> agg;
+  for (const KProf::Rec& r : h->kp.recs) {
+    if (r.cls != cls) continue;
+    for (const KNote& n : r.notes) {
+      bool found = false;
+      for (Agg& a : agg)
+        if (a.n.fn == n.fn && a.n.grid == n.grid && a.n.block == n.block && a.n.lds == n.lds) { a.count++; found = true; break; }
+      if (!found) agg.push_back(Agg{n, 1});
+    }
+  }
+  std::sort(agg.begin(), agg.end(), [](const Agg& a, const Agg& b) { return a.count > b.count; });
+  std::string out;
+  for (const Agg& a : agg) {
+    const char* mangled = hipKernelNameRefByPtr(a.n.fn, nullptr);
+    std::string name = mangled ? mangled : "?";
+    if (mangled) {
+      int st = 0;
+      char* d = abi::__cxa_demangle(mangled, nullptr, nullptr, &st);
+      if (st == 0 && d) name = d;
+      free(d);
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, a.n.fn, (int)a.n.block, a.n.lds) != hipSuccess) per_cu = 0;
+    char line[64];
+    snprintf(line, sizeof(line), "%ld\t%u\t%u\t%zu\t%d\t", a.count, a.n.grid, a.n.block, a.n.lds, per_cu);
+    out += line;
+    out += name;
+    out += "\n";
+  }
+  snprintf(buf, (size_t)cap, "%s", out.c_str());
   return 0;
 }
 
@@ -1977,7 +2074,7 @@ int fact_infer_ar(FactHandle* h, const float* motion_seed, const float* audio, i
   } skinny_scope(h, h->sr_rows != 0);
   struct InferScope {
     FactHandle* h;
-    explicit InferScope(FactHandle* hh) : h(hh) { h->keep_pre = getenv("FACT_KEEP_PRE") != nullptr; }  // env: A/B knob
+    explicit InferScope(FactHandle* hh) : h(hh) { h->keep_pre = h->keep_pre_infer; }  // debug option "keep_pre"
     ~InferScope() { h->keep_pre = true; }
   } infer_scope(h);
   for (int i = 0; i < nsteps; ++i) {
@@ -2247,7 +2344,7 @@ int fact_debug_cu_hog(int nwg, int micros, void* stream) {
   if (!sink) HIPCHK(hipMalloc((void**)&sink, 4));
   const int mode = nwg >> 16, n = nwg & 0xFFFF;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(cu_hog_kernel, dim3(n), dim3(256), (mode & 1) ? 1024 : 96 * 1024, (hipStream_t)stream,
+  FACT_LAUNCH(cu_hog_kernel, dim3(n), dim3(256), (mode & 1) ? 1024 : 96 * 1024, (hipStream_t)stream,
                      (long long)micros * 100, sink, mode);  // wall_clock64() ticks at 100 MHz
   return 0;
 }
@@ -2272,6 +2369,14 @@ int fact_debug_gemm_nt_band(int band) {
 int fact_op_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, float b1, float b2,
                  float eps, void* stream) {
   CHK(launch_adam(p, m, v, g, n, lr_t, b1, b2, eps, 1.0f, (hipStream_t)stream));
+  return 0;
+}
+
+int fact_loss(const float* target, const float* pred, int B, int n, int T, int D, float* loss_out, void* stream) {
+  if (!target || !pred || !loss_out) return fail(-1, "null argument");
+  if (B <= 0 || n <= 0 || T <= 0 || T > n || D <= 0) return fail(-1, "loss: need 0 < T <= n");
+  HIPCHK(hipMemsetAsync(loss_out, 0, sizeof(float), (hipStream_t)stream));
+  CHK(launch_mse_loss(pred, target, loss_out, nullptr, B, n, T, D, rup(D, 32), 1.0f, (hipStream_t)stream));
   return 0;
 }
 

@@ -898,7 +898,7 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
   const int tn = (p.N + BN - 1) / BN;
   const int tiles128 = tn * ((p.M + 127) / 128);
   if (p.force_generic || (p.K & 31)) {
-    hipLaunchKernelGGL((gemm_generic_kernel<EPI, false>), dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
+    FACT_LAUNCH((gemm_generic_kernel<EPI, false>), dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
     return 0;
   }
   int variant = g_nt_variant;
@@ -974,7 +974,7 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         once = true;
       }
-      hipLaunchKernelGGL((gemm_nt_big_kernel<EPI, 9>), dim3(((p.N + 255) / 256) * ((p.M + 287) / 288)), dim3(512),
+      FACT_LAUNCH((gemm_nt_big_kernel<EPI, 9>), dim3(((p.N + 255) / 256) * ((p.M + 287) / 288)), dim3(512),
                          LDSB, s, p);
       return 0;
     }
@@ -986,12 +986,12 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
         once = true;
       }
-      hipLaunchKernelGGL((gemm_nt_big_kernel<EPI, 8>), dim3(((p.N + 255) / 256) * ((p.M + 255) / 256)), dim3(512),
+      FACT_LAUNCH((gemm_nt_big_kernel<EPI, 8>), dim3(((p.N + 255) / 256) * ((p.M + 255) / 256)), dim3(512),
                          LDSB, s, p);
       return 0;
     }
   }
-  hipLaunchKernelGGL(gemm_nt_fast_kernel<EPI>, dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
+  FACT_LAUNCH(gemm_nt_fast_kernel<EPI>, dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
   return 0;
 }
 template <int EPI>
@@ -999,9 +999,9 @@ int launch_tn_t(const GemmParams& p, hipStream_t s) {
   const int tn = (p.N + BN - 1) / BN;
   dim3 grid(tn * ((p.M + BM - 1) / BM) * p.splitk);
   if ((p.K & 63) == 0 && p.lda >= 8 && p.ldb >= 8 && !p.force_generic) {
-    hipLaunchKernelGGL(gemm_tn_fast_kernel<EPI>, grid, dim3(256), 0, s, p);
+    FACT_LAUNCH(gemm_tn_fast_kernel<EPI>, grid, dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL((gemm_generic_kernel<EPI, true>), grid, dim3(256), 0, s, p);
+    FACT_LAUNCH((gemm_generic_kernel<EPI, true>), grid, dim3(256), 0, s, p);
   }
   return 0;
 }

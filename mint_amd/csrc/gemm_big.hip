@@ -1232,7 +1232,7 @@ int launch_big_nt_cfg(const GemmParams& p, hipStream_t s) {
       if ((p.splitk - 1) * per >= nk_all) return -9;
     }
   }
-  hipLaunchKernelGGL((big_nt_kernel<C, EPI>), dim3(tiles * p.splitk), dim3(C::NW * 64), C::LDS_BYTES, s, p);
+  FACT_LAUNCH((big_nt_kernel<C, EPI>), dim3(tiles * p.splitk), dim3(C::NW * 64), C::LDS_BYTES, s, p);
   return 0;
 }
 
@@ -1310,20 +1310,20 @@ int launch_skinny_epilogue(int epi, float* acc, int ldacc, const GemmParams& p_i
     if (epi != EPI_F32_BIAS_RESID || (p.N & 3) || p.N > 1024 || !p.ep.bias || !p.ep.resid || (p.ep.ldo0 & 3) || (p.ep.ldr & 3) ||
         (p.ep.ln_ldh & 3) || !p.ep.ln_g || !p.ep.ln_b || !p.ep.ln_mean || !p.ep.ln_rstd)
       return -9;
-    hipLaunchKernelGGL((skinny_epilogue_ln_kernel<4>), dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, acc, ldacc, p);
+    FACT_LAUNCH((skinny_epilogue_ln_kernel<4>), dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, s, acc, ldacc, p);
     return 0;
   }
   const int total = p.M * ((p.N + 3) >> 2);
   const dim3 grid((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), block(256);
   switch (epi) {
-    case EPI_BF16: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_BF16>, grid, block, 0, s, acc, ldacc, p); return 0;
-    case EPI_F32_BIAS: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_F32_BIAS>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_BF16: FACT_LAUNCH(skinny_epilogue_kernel<EPI_BF16>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_F32_BIAS: FACT_LAUNCH(skinny_epilogue_kernel<EPI_F32_BIAS>, grid, block, 0, s, acc, ldacc, p); return 0;
     case EPI_F32_BIAS_RESID:
-      hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_F32_BIAS_RESID>, grid, block, 0, s, acc, ldacc, p); return 0;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_BIAS_GELU>, grid, block, 0, s, acc, ldacc, p); return 0;
-    case EPI_GELU_BWD: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_GELU_BWD>, grid, block, 0, s, acc, ldacc, p); return 0;
-    case EPI_HEADS: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_HEADS>, grid, block, 0, s, acc, ldacc, p); return 0;
-    case EPI_F32_BF16: hipLaunchKernelGGL(skinny_epilogue_kernel<EPI_F32_BF16>, grid, block, 0, s, acc, ldacc, p); return 0;
+      FACT_LAUNCH(skinny_epilogue_kernel<EPI_F32_BIAS_RESID>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_BIAS_GELU: FACT_LAUNCH(skinny_epilogue_kernel<EPI_BIAS_GELU>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_GELU_BWD: FACT_LAUNCH(skinny_epilogue_kernel<EPI_GELU_BWD>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_HEADS: FACT_LAUNCH(skinny_epilogue_kernel<EPI_HEADS>, grid, block, 0, s, acc, ldacc, p); return 0;
+    case EPI_F32_BF16: FACT_LAUNCH(skinny_epilogue_kernel<EPI_F32_BF16>, grid, block, 0, s, acc, ldacc, p); return 0;
   }
   return -7;
 }
@@ -1354,7 +1354,7 @@ int launch_big_tn_group_t(TnGroup g, hipStream_t s, int parts) {
     const int lo = (int)((long long)total * i / parts), hi = (int)((long long)total * (i + 1) / parts);
     if (hi <= lo) continue;
     g.tile0 = lo;
-    hipLaunchKernelGGL((big_tn_kernel<C, PF>), dim3(hi - lo), dim3(C::NW * 64), C::LDS_BYTES, s, g);
+    FACT_LAUNCH((big_tn_kernel<C, PF>), dim3(hi - lo), dim3(C::NW * 64), C::LDS_BYTES, s, g);
   }
   return 0;
 }

@@ -1,6 +1,6 @@
 // Layout probes (diagnostics only): run one MFMA / one LDS transpose-read with caller-chosen
 // per-lane register contents so the host can verify the fragment layouts assumed in common.h.
-#include "../../include/fact_hip.h"
+#include "../../include/fact_hip_debug.h"
 #include "common.h"
 
 namespace {
@@ -32,11 +32,11 @@ __global__ void probe_tr_kernel(const float* vals, int n, const int* addrs, floa
 
 extern "C" {
 int fact_probe_mfma(const float* a_regs, const float* b_regs, float* d_regs, void* stream) {
-  hipLaunchKernelGGL(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a_regs, b_regs, d_regs);
+  FACT_LAUNCH(probe_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a_regs, b_regs, d_regs);
   return 0;
 }
 int fact_probe_tr(const float* lds_vals, int n, const int* byte_addrs, float* out, void* stream) {
-  hipLaunchKernelGGL(probe_tr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lds_vals, n, byte_addrs, out);
+  FACT_LAUNCH(probe_tr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, lds_vals, n, byte_addrs, out);
   return 0;
 }
 }

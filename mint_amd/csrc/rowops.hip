@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__
       part += diff * diff;
       g = 2.0f * diff * inv_count * gscale;
     }
-    dpred[(size_t)row * ldp + c] = (bf16_t)g;
+    if (dpred) dpred[(size_t)row * ldp + c] = (bf16_t)g;
   }
   if (t < T) {
     __shared__ float red[4];
@@ -952,11 +952,11 @@ int launch_ln_fwd(const float* x, const float* gamma, const float* beta, bf16_t*
                   float* rstd, int M, int C, float eps, hipStream_t s) {
   if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0 || ldh < C || (ldh & 3)) return -1;
   if (C <= 1024)
-    hipLaunchKernelGGL((ln_fwd_kernel<4>), dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd, M, C, ldh, eps);
+    FACT_LAUNCH((ln_fwd_kernel<4>), dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd, M, C, ldh, eps);
   else if (C <= 1536)
-    hipLaunchKernelGGL((ln_fwd_kernel<6>), dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd, M, C, ldh, eps);
+    FACT_LAUNCH((ln_fwd_kernel<6>), dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd, M, C, ldh, eps);
   else
-    hipLaunchKernelGGL((ln_fwd_kernel<LN_MAXV>), dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd, M, C, ldh,
+    FACT_LAUNCH((ln_fwd_kernel<LN_MAXV>), dim3((M + 3) / 4), dim3(256), 0, s, x, gamma, beta, h, mean, rstd, M, C, ldh,
                        eps);
   return 0;
 }
@@ -975,15 +975,15 @@ int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const flo
   const int grid = (M + rpb - 1) / rpb;
   const size_t shmem = (size_t)3 * 4 * C * sizeof(float);
   if (C <= 1024) {
-    hipLaunchKernelGGL((ln_bwd_kernel<4>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
+    FACT_LAUNCH((ln_bwd_kernel<4>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
                        dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, ws, M, C, ld16, rpb);
   } else {
-    hipLaunchKernelGGL((ln_bwd_kernel<8>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
+    FACT_LAUNCH((ln_bwd_kernel<8>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma,
                        dres, dx, dx_bf16, dgamma, dbeta, dbias_prev, ws, M, C, ld16, rpb);
   }
   if (ws) {
     dim3 g2((3 * C + 255) / 256, (grid + 31) / 32);
-    hipLaunchKernelGGL(colreduce_kernel, g2, dim3(256), 0, s, ws, grid, C, dgamma, dbeta,
+    FACT_LAUNCH(colreduce_kernel, g2, dim3(256), 0, s, ws, grid, C, dgamma, dbeta,
                        (dres ? dbias_prev : nullptr));
   }
   return 0;
@@ -994,13 +994,13 @@ int launch_ln_bwd_dx(const bf16_t* dh, const float* x, const float* mean, const 
   if ((C & 3) || C > 64 * 4 * LN_MAXV || M <= 0 || ld16 < C || (ld16 & 3)) return -1;
   const int grid = (M + 3) / 4;
   if (C <= 1024)
-    hipLaunchKernelGGL((ln_bwd_dx_kernel<4>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
+    FACT_LAUNCH((ln_bwd_dx_kernel<4>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
                        M, C, ld16);
   else if (C <= 1536)
-    hipLaunchKernelGGL((ln_bwd_dx_kernel<6>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
+    FACT_LAUNCH((ln_bwd_dx_kernel<6>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
                        M, C, ld16);
   else
-    hipLaunchKernelGGL((ln_bwd_dx_kernel<8>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
+    FACT_LAUNCH((ln_bwd_dx_kernel<8>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
                        M, C, ld16);
   return 0;
 }
@@ -1012,10 +1012,10 @@ int launch_ln_param_grads(const bf16_t* dh, int ld16, const float* x, const floa
   const int rpb = 128;
   dim3 grid((C + 255) / 256, (M + rpb - 1) / rpb);
   if (dy_is_f32)
-    hipLaunchKernelGGL((ln_param_grads_kernel<float>), grid, dim3(256), 0, s, dh, ld16, x, mean, rstd, (const float*)dy,
+    FACT_LAUNCH((ln_param_grads_kernel<float>), grid, dim3(256), 0, s, dh, ld16, x, mean, rstd, (const float*)dy,
                        ldy, dgamma, dbeta, dbias, M, C, rpb);
   else
-    hipLaunchKernelGGL((ln_param_grads_kernel<bf16_t>), grid, dim3(256), 0, s, dh, ld16, x, mean, rstd,
+    FACT_LAUNCH((ln_param_grads_kernel<bf16_t>), grid, dim3(256), 0, s, dh, ld16, x, mean, rstd,
                        (const bf16_t*)dy, ldy, dgamma, dbeta, dbias, M, C, rpb);
   return 0;
 }
@@ -1033,7 +1033,7 @@ int launch_col_tasks(ColTasks ts, hipStream_t s) {
     groups += ng;
   }
   ts.rpb = 128;
-  hipLaunchKernelGGL(col_tasks_kernel, dim3(groups, (ts.M + ts.rpb - 1) / ts.rpb), dim3(256), 0, s, ts);
+  FACT_LAUNCH(col_tasks_kernel, dim3(groups, (ts.M + ts.rpb - 1) / ts.rpb), dim3(256), 0, s, ts);
   return 0;
 }
 
@@ -1041,7 +1041,7 @@ int launch_colsum_bf16(const bf16_t* in, int ld, float* out, int M, int C, int C
   if ((C & 7) || (ld & 7)) return -1;
   const int rpb = 128;
   dim3 grid((C + 255) / 256, (M + rpb - 1) / rpb);
-  hipLaunchKernelGGL((colsum_kernel<bf16_t, 8>), grid, dim3(256), 0, s, in, ld, out, M, C, Cout, rpb);
+  FACT_LAUNCH((colsum_kernel<bf16_t, 8>), grid, dim3(256), 0, s, in, ld, out, M, C, Cout, rpb);
   return 0;
 }
 
@@ -1049,13 +1049,13 @@ int launch_colsum_f32(const float* in, int ld, float* out, int M, int C, int Cou
   if ((C & 3) || (ld & 3)) return -1;
   const int rpb = 128;
   dim3 grid((C + 127) / 128, (M + rpb - 1) / rpb);
-  hipLaunchKernelGGL((colsum_kernel<float, 4>), grid, dim3(256), 0, s, in, ld, out, M, C, Cout, rpb);
+  FACT_LAUNCH((colsum_kernel<float, 4>), grid, dim3(256), 0, s, in, ld, out, M, C, Cout, rpb);
   return 0;
 }
 
 int launch_possum(const float* dx, float* dpos, int B, int n, int C, hipStream_t s) {
   const size_t nC = (size_t)n * C;
-  hipLaunchKernelGGL(possum_kernel, dim3((unsigned)((nC + 255) / 256)), dim3(256), 0, s, dx, dpos, B, nC);
+  FACT_LAUNCH(possum_kernel, dim3((unsigned)((nC + 255) / 256)), dim3(256), 0, s, dx, dpos, B, nC);
   return 0;
 }
 
@@ -1063,7 +1063,7 @@ int launch_mse_loss(const float* pred, const float* target, float* loss_sum, bf1
                     int n, int T, int D, int ldp, float gscale, hipStream_t s) {
   if (T > n || D > ldp) return -1;
   const float inv_count = 1.0f / ((float)B * (float)T * (float)D);
-  hipLaunchKernelGGL(mse_loss_kernel, dim3(B * n), dim3(256), 0, s, pred, target, loss_sum, dpred, B, n,
+  FACT_LAUNCH(mse_loss_kernel, dim3(B * n), dim3(256), 0, s, pred, target, loss_sum, dpred, B, n,
                      T, D, ldp, inv_count, gscale);
   return 0;
 }
@@ -1072,7 +1072,7 @@ int launch_adam(float* p, float* m, float* v, float* g, size_t n, float lr_t, fl
                 float eps, float gscale, hipStream_t s) {
   if (n & 3) return -1;
   const size_t n4 = n >> 2;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, 256, 8192)), dim3(256), 0, s, (float4*)p,
+  FACT_LAUNCH(adam_kernel, dim3(grid_for(n4, 256, 8192)), dim3(256), 0, s, (float4*)p,
                      (float4*)m, (float4*)v, (float4*)g, n4, lr_t, b1, b2, eps, gscale);
   return 0;
 }
@@ -1085,21 +1085,21 @@ int launch_adam_fused(const AdamBlock* blocks, int nblocks, float* p, float* m, 
   // g_adam_variant: 0 = round-2 kernel (64x64 tiles), 1 = round-3 kernel plain accesses, 2 = ... non-temporal;
   // the tile width is a property of the block table (adam_tile_width()), fixed when the handle is created
   if (g_adam_variant == 0 && g_adam_tw == 64 && !keep)
-    hipLaunchKernelGGL(adam_fused_kernel, dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t, b1, b2, eps,
+    FACT_LAUNCH(adam_fused_kernel, dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t, b1, b2, eps,
                        gscale);
   else if (g_adam_tw == 128) {
     if (g_adam_variant == 2)
-      hipLaunchKernelGGL((adam_fused2_kernel<128, true>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
+      FACT_LAUNCH((adam_fused2_kernel<128, true>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
                          b1, b2, eps, gscale, keep);
     else
-      hipLaunchKernelGGL((adam_fused2_kernel<128, false>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
+      FACT_LAUNCH((adam_fused2_kernel<128, false>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
                          b1, b2, eps, gscale, keep);
   } else {
     if (g_adam_variant == 2)
-      hipLaunchKernelGGL((adam_fused2_kernel<64, true>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
+      FACT_LAUNCH((adam_fused2_kernel<64, true>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
                          b1, b2, eps, gscale, keep);
     else
-      hipLaunchKernelGGL((adam_fused2_kernel<64, false>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
+      FACT_LAUNCH((adam_fused2_kernel<64, false>), dim3(nblocks), dim3(256), 0, s, blocks, p, m, v, g, g16, lr_t,
                          b1, b2, eps, gscale, keep);
   }
   return 0;
@@ -1119,21 +1119,21 @@ int adam_tile_width() {
 int launch_cast_transpose(const float* src, int R, int C, bf16_t* dst, int ldd, bf16_t* dstT, int ldt,
                           hipStream_t s) {
   dim3 grid((C + 63) / 64, (R + 63) / 64);
-  hipLaunchKernelGGL((cast_transpose_kernel<float>), grid, dim3(256), 0, s, src, C, R, C, dst, ldd,
+  FACT_LAUNCH((cast_transpose_kernel<float>), grid, dim3(256), 0, s, src, C, R, C, dst, ldd,
                      dstT, ldt);
   return 0;
 }
 
 int launch_multi_cast_transpose(const CastDesc* descs, int n, int total_tiles, hipStream_t s) {
   if (n <= 0 || total_tiles <= 0) return 0;
-  hipLaunchKernelGGL(multi_cast_transpose_kernel, dim3(total_tiles), dim3(256), 0, s, descs, n);
+  FACT_LAUNCH(multi_cast_transpose_kernel, dim3(total_tiles), dim3(256), 0, s, descs, n);
   return 0;
 }
 
 int launch_transpose_bf16(const bf16_t* src, int ld, int R, int C, bf16_t* dstT, int ldt,
                           hipStream_t s) {
   dim3 grid((C + 63) / 64, (R + 63) / 64);
-  hipLaunchKernelGGL((cast_transpose_kernel<bf16_t>), grid, dim3(256), 0, s, src, ld, R, C,
+  FACT_LAUNCH((cast_transpose_kernel<bf16_t>), grid, dim3(256), 0, s, src, ld, R, C,
                      (bf16_t*)nullptr, 0, dstT, ldt);
   return 0;
 }
@@ -1141,21 +1141,21 @@ int launch_transpose_bf16(const bf16_t* src, int ld, int R, int C, bf16_t* dstT,
 int launch_pad_cast(const float* src, int n, size_t batch_stride, int M, int F, bf16_t* dst, int Fp,
                     hipStream_t s) {
   const size_t tot = (size_t)M * Fp;
-  hipLaunchKernelGGL(pad_cast_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, n,
+  FACT_LAUNCH(pad_cast_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, src, n,
                      batch_stride, M, F, dst, Fp);
   return 0;
 }
 
 int launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t s) {
   if (n & 3) return -1;
-  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, s, (const float4*)src,
+  FACT_LAUNCH(cast_bf16_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, s, (const float4*)src,
                      (bf16x4*)dst, n >> 2);
   return 0;
 }
 
 int launch_cast_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s) {
   if (n & 3) return -1;
-  hipLaunchKernelGGL(cast_f32_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, s, (const bf16x4*)src,
+  FACT_LAUNCH(cast_f32_kernel, dim3(grid_for(n >> 2, 256)), dim3(256), 0, s, (const bf16x4*)src,
                      (float4*)dst, n >> 2);
   return 0;
 }
@@ -1163,7 +1163,7 @@ int launch_cast_f32(const bf16_t* src, float* dst, size_t n, hipStream_t s) {
 int launch_concat_seq(const float* a, const float* b, int B, int na, int nb, int C, float* out, hipStream_t s) {
   if (C & 3) return -1;
   const size_t total = (size_t)B * (na + nb) * (C >> 2);
-  hipLaunchKernelGGL(concat_seq_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)a,
+  FACT_LAUNCH(concat_seq_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)a,
                      (const float4*)b, B, na, nb, C >> 2, (float4*)out);
   return 0;
 }
@@ -1172,7 +1172,7 @@ int launch_gather_rows(const float* x, const bf16_t* a, int B, int n, int T, int
                        hipStream_t s) {
   if ((C & 3) || (ld16 & 3) || ld16 < C || T > n) return -1;
   const size_t total = (size_t)B * T * (C >> 2);
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)x,
+  FACT_LAUNCH(gather_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)x,
                      (const bf16x4*)a, B, n, T, C >> 2, ld16 >> 2, (float4*)xc, (bf16x4*)ac);
   return 0;
 }
@@ -1180,7 +1180,7 @@ int launch_gather_rows(const float* x, const bf16_t* a, int B, int n, int T, int
 int launch_scatter_rows_zero(const float* dxc, int B, int n, int T, int C, float* dx, hipStream_t s) {
   if ((C & 3) || T > n) return -1;
   const size_t total = (size_t)B * n * (C >> 2);
-  hipLaunchKernelGGL(scatter_rows_zero_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)dxc, B, n, T,
+  FACT_LAUNCH(scatter_rows_zero_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)dxc, B, n, T,
                      C >> 2, (float4*)dx);
   return 0;
 }
@@ -1189,7 +1189,7 @@ int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, 
                       bf16_t* db16, int ld16, hipStream_t s) {
   if ((C & 3) || ld16 < C || (ld16 & 3)) return -1;
   const size_t total = (size_t)B * (na + nb) * (C >> 2);
-  hipLaunchKernelGGL(split_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)dx,
+  FACT_LAUNCH(split_grad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, (const float4*)dx,
                      B, na, nb, C >> 2, ld16 >> 2, (float4*)da, (bf16x4*)da16, (float4*)db, (bf16x4*)db16);
   return 0;
 }
@@ -1197,14 +1197,14 @@ int launch_split_grad(const float* dx, int B, int na, int nb, int C, float* da, 
 int launch_slab_reduce(const float* slabs, size_t stride, int nslab, float* out, size_t n, hipStream_t s) {
   if ((stride & 3) || ((uintptr_t)out & 15) || ((uintptr_t)slabs & 15)) return -1;
   const size_t n4 = n >> 2;
-  if (n4) hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, s, slabs, stride, nslab, out, n4);
-  if (n & 3) hipLaunchKernelGGL(slab_reduce_tail_kernel, dim3(1), dim3(64), 0, s, slabs, stride, nslab, out, n4 << 2, n);
+  if (n4) FACT_LAUNCH(slab_reduce_kernel, dim3(grid_for(n4, 256, 2048)), dim3(256), 0, s, slabs, stride, nslab, out, n4);
+  if (n & 3) FACT_LAUNCH(slab_reduce_tail_kernel, dim3(1), dim3(64), 0, s, slabs, stride, nslab, out, n4 << 2, n);
   return 0;
 }
 
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s) {
   if (n & 3) return -1;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, s,
+  FACT_LAUNCH(sumsq_kernel, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, s,
                      (const float4*)g, n >> 2, out);
   return 0;
 }

@@ -72,6 +72,7 @@ class FACTModel:
         self._loss_buf = None
         self._grad_cb = None
         self._grad_cb_args = None
+        self._options = {}  # engine options set through set_option / debug_option: key -> (value, debug); re-applied by build()
 
     # ------------------------------------------------------------------------------------------
     def _cfg_struct(self):
@@ -143,6 +144,8 @@ class FACTModel:
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=self._device)
         if self._grad_cb_args is not None:  # handle was re-created: re-register the bucket callback
             self.set_grad_callback(*self._grad_cb_args)
+        for key, (value, debug) in self._options.items():  # options are per handle: a re-created handle gets them again
+            self._apply_option(key, value, debug)
         if getattr(self, "_pending_state", None) is not None:
             state, self._pending_state = self._pending_state, None
             self.load_state_dict(state)
@@ -229,11 +232,8 @@ class FACTModel:
         target, pred = self._prep(target), self._prep(pred)
         B, T, D = target.shape
         n = pred.shape[1]
-        ldp = (D + 31) // 32 * 32
         loss = torch.zeros(1, dtype=torch.float32, device=self._device)
-        scratch = torch.empty(B * n, ldp, dtype=torch.bfloat16, device=self._device)
-        L.check(L.lib().fact_op_mse(L.ptr(pred), L.ptr(target), L.ptr(loss), L.ptr(scratch), B, n, T, D, ldp,
-                                    1.0, L.cur_stream()))
+        L.check(L.lib().fact_loss(L.ptr(target), L.ptr(pred), B, n, T, D, L.ptr(loss), L.cur_stream()))
         return loss[0]
 
     def compute_motion_generation_loss(self, pred_tensors, target_tensors):
@@ -363,16 +363,48 @@ class FACTModel:
         names = (C.c_char_p * cap)()
         arrs = [(C.c_double * cap)() for _ in range(4)]
         L.check(lib.fact_kprof_read(self._h, cap, C.byref(n), names, *arrs))
-        return [{"name": names[i].decode(), "launches": arrs[0][i], "total_ms": arrs[1][i], "flops": arrs[2][i],
-                 "bytes": arrs[3][i]} for i in range(n.value)]
+        out = []
+        buf = C.create_string_buffer(16384)
+        for i in range(n.value):
+            # the kernels the recorder saw behind this class: symbol (as rocprofv3 prints it), grid, block, LDS, occupancy
+            L.check(lib.fact_kprof_kernels(self._h, i, buf, len(buf)))
+            kernels = []
+            for line in buf.value.decode(errors="replace").splitlines():
+                f = line.split("\t", 5)
+                if len(f) == 6:
+                    kernels.append({"count": int(f[0]), "grid": int(f[1]), "block": int(f[2]), "lds_bytes": int(f[3]),
+                                    "workgroups_per_cu": int(f[4]), "name": f[5]})
+            out.append({"name": names[i].decode(), "launches": arrs[0][i], "total_ms": arrs[1][i], "flops": arrs[2][i],
+                        "bytes": arrs[3][i], "kernels": kernels})
+        return out
+
+    def _apply_option(self, key, value, debug):
+        fn = L.lib().fact_debug_set_option if debug else L.lib().fact_set_option
+        L.check(fn(self._h, key.encode(), int(value)))
 
     def set_option(self, key, value):
+        """Engine option of the production surface (include/fact_hip.h: sr_rows, grad_overwrite, side_stream,
+        aux_stream).  Remembered and re-applied when build() re-creates the handle for a larger batch - options are
+        per handle, and e.g. a trainer that set grad_overwrite must not silently fall back to accumulation."""
+        if key not in L.PUBLIC_OPTIONS:
+            raise ValueError("%r is not a production option %s; test / bench knobs: debug_option()" % (
+                key, list(L.PUBLIC_OPTIONS)))
         self._require_built()
-        L.check(L.lib().fact_set_option(self._h, key.encode(), int(value)))
+        self._apply_option(key, value, False)
+        self._options[key] = (int(value), False)
+
+    def debug_option(self, key, value):
+        """Test / bench knob (include/fact_hip_debug.h, fact_debug_set_option): kernel-selection and scheduling A/B
+        switches, the timing-only ablation mask.  Not for production hosts."""
+        self._require_built()
+        self._apply_option(key, value, True)
+        self._options[key] = (int(value), key not in L.PUBLIC_OPTIONS)
 
     def state_dict(self):
         self._require_built()
-        d = {k: v.detach().cpu().clone() for k, v in self._arena.items()}
+        # the gradient arena is transient (zero between optimizer steps; under grad_overwrite partly stale by design): it is
+        # neither saved nor restored
+        d = {k: v.detach().cpu().clone() for k, v in self._arena.items() if k != "grads"}
         d["global_step"] = int(self.global_step)
         d["variable_names"] = self.variable_names
         return d
@@ -383,7 +415,9 @@ class FACTModel:
             self.global_step = int(state.get("global_step", 0))
             return
         for k in self._arena:
-            if k in state:
+            if k == "grads":
+                self._arena[k].zero_()
+            elif k in state:
                 self._arena[k].copy_(state[k])
         self.global_step = int(state.get("global_step", 0))
         L.check(L.lib().fact_set_step(self._h, int(self.global_step)))

@@ -125,10 +125,7 @@ class OverlappedGradReducer:
         # Launchers should export GPU_MAX_HW_QUEUES=7 before the HIP runtime starts (bench.py does for N > 1).
         # `keep_streams_low` folds the engine's third stream instead (no measurable help at 4 queues: 11.4 vs 11.0).
         if keep_streams_low and hasattr(model, "set_option"):
-            try:
-                model.set_option("aux_stream", 0)
-            except Exception:
-                pass
+            model.set_option("aux_stream", 0)
 
     def _stream(self):
         import contextlib
@@ -285,11 +282,10 @@ class SingleTaskTrainer:
             # instead of accumulated, and the optimizer pass need not zero them (engine option grad_overwrite)
             if hasattr(self.model, "ensure_built"):
                 self.model.ensure_built(inputs)
-            try:
-                import os
-                self.model.set_option("grad_overwrite", int(os.environ.get("FACT_GRAD_OVERWRITE", "1")))
-            except Exception:
-                pass
+            import os
+            # not swallowed if it fails: a trainer that believes the option is on while the engine accumulates (or the
+            # reverse) corrupts a step silently.  FACTModel remembers the option and re-applies it to re-created handles.
+            self.model.set_option("grad_overwrite", int(os.environ.get("FACT_GRAD_OVERWRITE", "1")))
             self._grad_overwrite_set = True
         if self._overlap and self._reducer is None:
             self._reducer = OverlappedGradReducer(self.model, bf16_buckets=self._bf16_buckets)

@@ -53,6 +53,20 @@ def test_executed_fraction_of_the_supervised_rows_shortcut(bench):
     assert bench.executed_flop_fraction(target_len=360) == pytest.approx(1.0)
 
 
-def test_kernel_symbol_table_names_the_classes_the_engine_times(bench):
-    for cls in ("wgrad_group", "attention_fwd", "attention_bwd", "ffn1+gelu", "adam+shadows", "ln_bwd_dx"):
-        assert cls in bench.KERNEL_SYMBOLS
+def test_kernel_name_and_cu_share_come_from_the_engine_record(bench):
+    """The `kernel` / `cu_share` of a bench row are derived from what the engine's recorder saw launched (symbol, grid,
+    occupancy), not from a hand-kept table: most frequent launch shape first, CUs held = ceil(grid / workgroups per CU)."""
+    rec = {"name": "attention_bwd", "kernels": [
+        {"count": 24, "grid": 160, "block": 768, "lds_bytes": 147456, "workgroups_per_cu": 1, "name": "dq<80, 0>(AttnParams)"},
+        {"count": 24, "grid": 160, "block": 512, "lds_bytes": 150528, "workgroups_per_cu": 1, "name": "dkdv<80, 0>(AttnParams)"},
+        {"count": 8, "grid": 160, "block": 512, "lds_bytes": 100352, "workgroups_per_cu": 1, "name": "dq<80, 0>(AttnParams)"}]}
+    ck = bench.class_kernels(rec)
+    assert ck["kernel"] == "dq<80, 0>(AttnParams) + dkdv<80, 0>(AttnParams)"
+    assert ck["cus_held"] == 160 and ck["cu_share"] == 0.625
+    two = bench.class_kernels({"name": "out_proj+resid", "kernels": [
+        {"count": 12, "grid": 162, "block": 512, "lds_bytes": 73728, "workgroups_per_cu": 2, "name": "big_nt<...>"}]})
+    assert two["cus_held"] == 81
+    full = bench.class_kernels({"name": "ln_fwd", "kernels": [
+        {"count": 31, "grid": 1440, "block": 256, "lds_bytes": 0, "workgroups_per_cu": 8, "name": "ln_fwd_kernel<4>"}]})
+    assert full["cus_held"] == 180
+    assert bench.class_kernels({"name": "x", "kernels": []}) == {"kernel": "x", "cu_share": None}

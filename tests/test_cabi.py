@@ -9,11 +9,12 @@ import pytest
 from mint_amd import _lib as L
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "fact_hip.h")
+HEADER = os.path.join(ROOT, "include", "fact_hip.h")              # the drop-in boundary
+DEBUG_HEADER = os.path.join(ROOT, "include", "fact_hip_debug.h")  # test / bench surface, not for production hosts
 
 
-def _declared():
-    text = open(HEADER).read()
+def _declared(path=HEADER):
+    text = open(path).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fact_[a-z0-9_]+)\s*\(", text)))
 
@@ -27,13 +28,26 @@ def lib():
 
 
 def test_header_symbols_are_exported_and_bound(lib):
-    names = _declared()
-    assert len(names) >= 25
-    for n in names:
+    public, debug = _declared(), _declared(DEBUG_HEADER)
+    assert len(public) >= 20 and len(debug) >= 20 and not set(public) & set(debug)
+    for n in public + debug:
         assert hasattr(lib, n), "libfact_hip.so does not export %s" % n
         assert n in L.SIGNATURES, "mint_amd/_lib.py has no ctypes signature for %s" % n
     for n in L.SIGNATURES:
-        assert n in names, "%s bound in _lib.py but not declared in include/fact_hip.h" % n
+        assert n in public or n in debug, "%s bound in _lib.py but declared in neither header" % n
+    assert set(debug) == set(L.DEBUG_SYMBOLS)
+
+
+def test_public_header_carries_no_lab_bench():
+    """The header a maintainer binds is the SURVEY 8(b) surface only: no single-op / probe / recorder entry points, no
+    fact_debug_* switch, and no option key that selects kernels or - like the timing-only ablation mask - changes results."""
+    text = open(HEADER).read()
+    for n in _declared():
+        assert not n.startswith(("fact_debug", "fact_op_", "fact_probe", "fact_kprof")), n
+    block = text[text.index("/* Engine options"):text.index("int fact_set_option")]
+    keys = set(re.findall(r'^ \*   "([a-z0-9_]+)"', block, flags=re.M))
+    assert keys == set(L.PUBLIC_OPTIONS), keys
+    assert '"skip"' not in text and "attn_variant" not in text and "tn_loop" not in text
 
 
 def test_abi_version_and_struct_layout(lib):
@@ -66,17 +80,22 @@ def test_product_path_has_no_cpu_fallback():
         assert "from oracle" not in open(path).read() and "import oracle" not in open(path).read()
 
 
+def _accepted(engine, fn):
+    body = engine[engine.index("int %s(FactHandle* h, const char* key, int value) {" % fn):]
+    body = body[:body.index("\n}\n")]
+    return set(re.findall(r'!strcmp\(key, "([a-z0-9_]+)"\)', body))
+
+
 def test_documented_options_exist_in_the_engine():
-    """Every option key the header documents for fact_set_option is one the engine accepts (and the A/B knobs the
-    engine accepts are documented): the comment block is the only specification of that string-keyed interface."""
-    text = open(HEADER).read()
-    block = text[text.index("/* Engine knobs"):text.index("int fact_set_option")]
-    documented = set(re.findall(r'"([a-z0-9_]+)"', block))
+    """Every option key a header documents is one that entry point accepts, and every key the engine accepts is
+    documented in the header of ITS entry point: the comment blocks are the only specification of the two string-keyed
+    interfaces, and the production one accepts nothing but the production keys."""
     engine = open(os.path.join(ROOT, "mint_amd", "csrc", "engine.hip")).read()
-    body = engine[engine.index("int fact_set_option(FactHandle* h, const char* key, int value) {"):]
-    body = body[:body.index("\nint fact_forward(")]
-    accepted = set(re.findall(r'!strcmp\(key, "([a-z0-9_]+)"\)', body))
-    assert documented, "no option names found in the header comment"
-    assert documented <= accepted, "documented but not accepted: %s" % sorted(documented - accepted)
-    undocumented = accepted - documented
-    assert not undocumented, "accepted by fact_set_option but missing from include/fact_hip.h: %s" % sorted(undocumented)
+    text = open(HEADER).read()
+    block = text[text.index("/* Engine options"):text.index("int fact_set_option")]
+    assert set(re.findall(r'^ \*   "([a-z0-9_]+)"', block, flags=re.M)) == _accepted(engine, "fact_set_option") == set(L.PUBLIC_OPTIONS)
+    dtext = open(DEBUG_HEADER).read()
+    dblock = dtext[dtext.index("/* Test / bench knobs"):dtext.index("int fact_debug_set_option")]
+    documented = set(re.findall(r'"([a-z0-9_]+)"', dblock))
+    accepted = _accepted(engine, "fact_debug_set_option")
+    assert documented and documented == accepted, (sorted(documented - accepted), sorted(accepted - documented))
