@@ -28,7 +28,7 @@ import sys
 import time
 
 # Data-parallel runs add a communication stream and RCCL's own to the engine's three: with HIP's default of 4
-# hardware queues some of them share a queue and serialise (one-GPU dry run with RCCL initialised, tools/dp_probe.py:
+# hardware queues some of them share a queue and serialise (one-GPU dry run with RCCL initialised, tools/attic/dp_probe.py:
 # 11.4 ms per step at 4 queues, 8.2 at 7, 16.5 at 8).  Must be set before the HIP runtime starts.
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "7")

@@ -30,7 +30,7 @@ namespace {
 
 // bf16 row pitches are multiples of 64 elements (128 B): a 64-deep K-step chunk of a row is then
 // exactly one cache line (an 800-wide row at pitch 800 straddles two lines on every odd row, which
-// costs ~10 % of the K = 800 GEMMs - tools/gemm_bench.py).
+// costs ~10 % of the K = 800 GEMMs - tools/attic/gemm_bench.py).
 constexpr int kPitch = 64;
 
 thread_local std::string g_err;
@@ -755,7 +755,7 @@ int wgrad(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf16_t* B, int 
   if (!slab) slab = h->slab;
   const int tiles = ((Mo + 127) / 128) * ((No + 127) / 128);
   const int ktiles = (K + 63) / 64;
-  // ~2 blocks per CU: measured optimum on MI355X (tools/gemm_bench.py: 168 tiles -> 3, 49 -> 5..8)
+  // ~2 blocks per CU: measured optimum on MI355X (tools/attic/gemm_bench.py: 168 tiles -> 3, 49 -> 5..8)
   int splitk = 560 / tiles;
   if (splitk > 6) splitk = 6;
   if (splitk > ktiles / 4) splitk = ktiles / 4;
@@ -1827,7 +1827,7 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   hipStream_t ms = (h->use_side && h->use_aux && h->aux) ? h->aux : s;
   if (ms != s) stream_after(h, s, ms);
   // (audio first: its big-tile GEMMs need whole CUs; enqueued second they wait ~0.5 ms behind the motion
-  //  chain's one-workgroup-per-CU kernels - rocprofv3 timeline, tools/tail_view.py)
+  //  chain's one-workgroup-per-CU kernels - rocprofv3 timeline, tools/attic/tail_view.py)
   g16 = h->dxa16;
   for (int l = au.L - 1; l >= 0; --l) CHK(layer_backward(h, au, l, B, h->dxa, g16, s, h->bw[0]));
   CHK(flush_batch(h, h->bw[0]));
@@ -2314,7 +2314,7 @@ int fact_debug_attn_force_tiled(int on) {
 }
 // Occupies `nwg` CUs for ~`micros` microseconds: one 256-thread workgroup per CU (96 KiB of LDS each keeps a second one
 // off the CU), spinning on the shader clock.  Stand-in for a communication kernel that holds CUs while the step runs
-// (tools/cu_hog_probe.py: what does the train step lose when N CUs are not available to it?).
+// (tools/attic/cu_hog_probe.py: what does the train step lose when N CUs are not available to it?).
 __global__ __launch_bounds__(256) void cu_hog_kernel(long long cycles, unsigned* sink, int mode) {
   extern __shared__ unsigned char hog_lds[];
   unsigned acc = 0;

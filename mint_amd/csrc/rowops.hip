@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(const AdamBlock* __rest
 // step), (b) every load of a group of row passes issued before the first use, (c) 64 x TW tiles (TW = 64 or 128: 256- or
 // 512-byte row runs) and (d) no zero write-back of the gradient where the block says its producer overwrites it
 // (AdamBlock::pad[0] & 1: Dense kernels whose weight gradient comes from the whole-K grouped wgrad launch, engine option
-// grad_overwrite).  tools/adam_probe.hip: a flat kernel with today's access mix streams 5.85 TB/s, 6.3 with non-temporal
+// grad_overwrite).  tools/attic/adam_probe.hip: a flat kernel with today's access mix streams 5.85 TB/s, 6.3 with non-temporal
 // accesses, and the 32 B/param mix (no zeroing) finishes in 0.63-0.64 ms against 0.74 for 36 B/param.
 DEVINL f32x4 ld4(const float* p, bool nt) {
   return nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)) : *reinterpret_cast<const f32x4*>(p);

@@ -75,7 +75,7 @@ _EVENT = "__copy_done__"
 
 class _DeviceStager:
     """Host-to-device staging of batches: a ring of PRE-PINNED host buffers and a dedicated copy stream; the consumer's
-    stream waits for the batch's event (`_join_copies`).  Measured on MI355X (tools/e2e_probe.py, fact_v5 B = 16 train
+    stream waits for the batch's event (`_join_copies`).  Measured on MI355X (tools/attic/e2e_probe.py, fact_v5 B = 16 train
     step): resident batch 8.01 ms; this scheme 8.02 ms; `pin_memory().to(device, non_blocking=True)` per batch - the
     round-1 code - 16.7 ms (the freshly pinned temporary is released while its copy is in flight); pageable `.to(device)`
     8.19 ms."""
@@ -131,7 +131,7 @@ def create_input(train_eval_config, dataset_config, num_cpu_threads=2, is_traini
     `cache_decoded_bytes`: training repeats the files forever and cuts ONE 360-frame window out of a multi-thousand
     frame track per visit, so the decoded tracks of a file are kept (up to this many bytes in total; 0 = re-read and
     re-parse every epoch like tf.data does).  One MI355X consumes ~2 000 windows/s (bench.py); parsing a 2.3 MB
-    Example per window in Python delivers ~1 300/s, windows cut from cached tracks ~9 000/s (tools/input_bench.py).
+    Example per window in Python delivers ~1 300/s, windows cut from cached tracks ~9 000/s (tools/attic/input_bench.py).
     Order, shuffling and the random windows are unchanged by the cache."""
     batch_size = train_eval_config.batch_size
     files = sorted(_glob.glob(dataset_config.data_files))

@@ -120,7 +120,7 @@ class OverlappedGradReducer:
         self._prof_finish = []   # (event before finish, event after) per profiled step
         model.set_grad_callback(self._on_bucket, self.comm)
         # This stream and RCCL's own join the engine's three: more streams than the 4 hardware queues HIP uses by
-        # default, and streams that share a queue serialise (one-GPU dry run with RCCL initialised, tools/dp_probe.py:
+        # default, and streams that share a queue serialise (one-GPU dry run with RCCL initialised, tools/attic/dp_probe.py:
         # 11.4 ms per step at GPU_MAX_HW_QUEUES = 4, 8.6 at 6, 8.2 at 7 - the single-replica speed - and 16.5 at 8).
         # Launchers should export GPU_MAX_HW_QUEUES=7 before the HIP runtime starts (bench.py does for N > 1).
         # `keep_streams_low` folds the engine's third stream instead (no measurable help at 4 queues: 11.4 vs 11.0).

@@ -18,7 +18,7 @@ def main():
     p0 = model._arena["params"].clone()
     ref = None
     for variant in [int(x) for x in os.environ.get("VARIANTS", "0,1,2").split(",")]:
-        model.set_option("adam_variant", variant)
+        model.debug_option("adam_variant", variant)
         for k in ("adam_m", "adam_v"):
             model._arena[k].zero_()
         model._arena["params"].copy_(p0)
@@ -50,7 +50,7 @@ def main():
         ms = e0.elapsed_time(e1) / 20
         print("adam_variant %d tw %s: %.3f ms  %.0f GB/s (36 B/param)  identical_to_first %s  max|g| after %.1e"
               % (variant, os.environ.get("FACT_ADAM_TW", "64"), ms, n * 36 / ms / 1e6, same, gz), flush=True)
-    model.set_option("adam_variant", 0)
+    model.debug_option("adam_variant", 0)
 
 
 if __name__ == "__main__":

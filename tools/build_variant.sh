@@ -2,7 +2,7 @@
 # Build a variant of the library with extra compile flags for ONE translation unit and link it beside the shipped objects:
 #   tools/build_variant.sh w12 gemm_big -DFACT_EXPERIMENTAL_W12      -> tools/bin/libfact_w12.so
 #   tools/build_variant.sh pm2 gemm_big -DBIG_DMA_IN_MFMA=2
-# tools/bin/ is git-ignored but travels to the GPU box; A/B against the tree's library with tools/ab_libs.sh, or load it
+# tools/bin/ is git-ignored but travels to the GPU box; A/B against the tree's library with tools/attic/ab_libs.sh, or load it
 # with FACT_LIB=tools/bin/libfact_w12.so (mint_amd/_lib.py) for tools/bench_r2.py.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)

@@ -12,7 +12,7 @@ batch = {"motion_input": torch.randn(B, 120, 225, generator=gen).cuda(), "audio_
          "target": torch.randn(B, 20, 225, generator=gen).cuda()}
 model.build(B, 225, 35)
 for kv in sys.argv[2:]:
-    k, v = kv.split("="); model.set_option(k, int(v))
+    k, v = kv.split("="); model.debug_option(k, int(v))
 class Rep:
     def __iter__(self): return self
     def __next__(self): return batch
