@@ -31,7 +31,7 @@ int fact_kprof_kernels(FactHandle* h, int cls, char* buf, int cap);
  *   "wgrad_tr"       1 = wgrad GEMM builds its fragments with the LDS transpose read, 0 = explicit transposes
  *   "wgrad_slab"     1 = split-K partials as plain stores + a streaming reduce, 0 = fp32 atomics
  *   "fuse_adam_cast" 1 = Adam writes the bf16 weight shadows itself, 0 = Adam, then a cast/transpose pass
- *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "bwd_splitk", "adam_hold", "ln_fuse", "lite_stream", "keep_pre":
+ *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "ln_cs", "bwd_splitk", "adam_hold", "ln_fuse", "lite_stream", "keep_pre":
  *                    scheduling / fusion switches of the A/B runs documented in DESIGN.md sections 3 and 6
  *   "tn_loop", "attn_variant", "adam_variant", "big_impl", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on
  *                    64-deep ring slots; default 3): PROCESS-WIDE kernel selection
@@ -92,8 +92,10 @@ int fact_debug_gemm_big_impl(int v); /* 1 = gemm_big.hip family (default), 0 = r
 int fact_debug_gemm_nt_variant(int v);
 /* Test/bench knob: NT GEMM tile band height (tile order inside an XCD; 1 = row-major, default 8). */
 int fact_debug_gemm_nt_band(int band);
-/* Test/bench knob: LayerNorm-backward rows per workgroup (multiple of 4, >= 8); use_ws != 0 makes
- * fact_op_ln_bwd use the engine's partial-sum workspace path instead of atomics. */
+/* Test/bench knob of fact_op_ln_bwd: LayerNorm-backward rows per workgroup of the round-1 fused kernel (multiple of 4,
+ * >= 8); use_ws: 0 = round-2 split (column-sum kernel + row-wise dx kernel), 1 / 2 = round-1 fused kernel with the
+ * partial-sum workspace / with atomics, 3 / 4 = round-4 engine form (dx kernel leaving per-workgroup column-sum
+ * partials, 4 / 2 rows per wave, + reduce). */
 int fact_debug_ln_bwd(int rows_per_block, int use_ws);
 
 #ifdef __cplusplus

@@ -129,6 +129,8 @@ struct PendingBatch {
   Stack* st = nullptr;
   int l = 0, M = 0, q = 0;
   const bf16_t *xin16 = nullptr, *dpre = nullptr, *xmid16 = nullptr, *dqkv = nullptr, *dh2 = nullptr, *dh1 = nullptr;
+  const float *part2 = nullptr, *part1 = nullptr;  // ln_cs: column-sum partials of LayerNorm 2 / 1 (null: col_tasks path)
+  int part_blocks = 0;
   hipStream_t s = nullptr, w = nullptr;
   float* slab = nullptr;
 };
@@ -160,6 +162,7 @@ struct BwScratch {
   bf16_t* xb_pp[kBwBuf] = {};     // bf16 gradient at the layer boundary (output of the layer of parity q)
   bf16_t* dh2_pp[kBwBuf] = {};    // dgrad outputs feeding the two LayerNorm backward kernels (also read by the
   bf16_t* dh1_pp[kBwBuf] = {};    //   parameter-gradient column sums on the wgrad stream)
+  float* lnpart_pp[kBwBuf][2] = {};  // ln_cs: per-workgroup column-sum partials of the two LayerNorm backward kernels (LN2, LN1)
   hipEvent_t ev_batch[kBwBuf] = {};  // wgrad batch of the last layer of parity q finished
   hipEvent_t ev_waited = nullptr;    // last batch event the chain has already waited for
   PendingBatch pend;
@@ -243,6 +246,10 @@ struct FactHandle {
   int wgrad_slab = 1;
   int wgrad_big = 1;  // whole-K grouped big-tile wgrad launch per layer (gemm_big.hip)
   int ln_split = 1;   // LayerNorm backward: row-wise dx kernel on the chain, parameter gradients on the wgrad stream
+  int ln_cs = 0;      // (with ln_split) 1 / 2: the dx kernel leaves the column sums as per-workgroup partials (4 / 2 rows per
+                      // wave), a small reduce on the wgrad stream replaces the column-sum pass over dh / x / dy.  Round 4:
+                      // parity green, step unchanged (7.65 vs 7.66 ms: the dx kernel pays 22 -> 33 us on the dgrad chain for the
+                      // 50 -> 3 x 15 us it takes off the wgrad stream) - off by default, DESIGN 6
   int wgrad_parts = 2;   // launches per layer of the grouped wgrad kernel (each ~190/parts workgroups wide)
   int wgrad_defer = 1;   // release a layer's wgrad batch behind the NEXT layer's GELU' dgrad (240 workgroups)
   int bwd_splitk = 0;    // in-kernel split-K for the N = 800 dgrad GEMMs: 1 = always, 2 = stacks of <= 4096 rows (encoders)
@@ -561,6 +568,8 @@ void layout_work(FactHandle* h, Bump& b) {
         sc.xb_pp[q] = b.take<bf16_t>(Mx * dp);
         sc.dh2_pp[q] = b.take<bf16_t>(Mx * dp);
         sc.dh1_pp[q] = b.take<bf16_t>(Mx * dp);
+        sc.lnpart_pp[q][0] = b.take<float>(ln_cs_part_floats((int)Mx, d));
+        sc.lnpart_pp[q][1] = b.take<float>(ln_cs_part_floats((int)Mx, d));
       }
       sc.dorow = b.take<bf16_t>(rows);
       sc.dsum = b.take<float>(lse);
@@ -1064,9 +1073,23 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
   }
   // the HBM-bound column sums share CUs with anything: their own stream, so they run beside the wgrad launches
   // instead of behind them (the wgrad stream was as long as the dgrad chain with them in line)
-  hipStream_t c = (two && h->use_lite && h->lite && w == h->side) ? h->lite : w;
+  // use_lite: 1 = the handle's own extra stream, 2 = the third (aux) stream, which idles while the cross-modal stack runs
+  hipStream_t c = w;
+  if (two && w == h->side) {
+    if (h->use_lite == 1 && h->lite) c = h->lite;
+    else if (h->use_lite == 2 && h->aux && h->use_aux) c = h->aux;
+  }
   if (c != w) (void)hipStreamWaitEvent(c, rel, 0);  // same release event as the wgrad launches
-  if (h->ln_split) {
+  if (h->ln_split && b.part2) {
+    // ln_cs: the two LayerNorm backward kernels of the chain already left their column sums as per-workgroup partials;
+    // what remains is the dense_1 bias (column sum of dpre) and two small reduces over those partial rows
+    KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * ff * 2.0 + 2.0 * b.part_blocks * 3.0 * d * 4.0, 3);
+    if (!(h->skip & 2)) {
+      CHK(launch_colsum_bf16(b.dpre, fp, G(h, p.b1), M, ff, ff, c));
+      CHK(launch_colreduce(b.part2, b.part_blocks, d, G(h, p.ln2_g), G(h, p.ln2_b), G(h, p.b2), c));
+      CHK(launch_colreduce(b.part1, b.part_blocks, d, G(h, p.ln1_g), G(h, p.ln1_b), G(h, p.bo), c));
+    }
+  } else if (h->ln_split) {
     // ONE launch: the dense_1 bias (column sum of dpre) and, per LayerNorm, gamma / beta from the dgrad output
     // plus the bias gradient of the GEMM that fed the residual add (dense_2 / to_out) = column sum of the
     // gradient that entered it, taken from its bf16 copy (xin16 / xmid16)
@@ -1147,8 +1170,14 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
     if (!(h->skip & 32)) CHK(launch_gemm_nt(EPI_BF16, g, s));
   }
   KScope* kln = new KScope(h, KP_LN_BWD, s, 0, Md * d * 16.0);
+  // (the batch must be flushed AFTER this layer's LayerNorm 1 backward has produced its partials: wgrad_defer)
+  const bool cs = split && h->ln_cs && h->wgrad_defer && d <= 1024;
+  float* part2 = cs ? sc.lnpart_pp[q][0] : nullptr;
+  float* part1 = cs ? sc.lnpart_pp[q][1] : nullptr;
   if (h->skip & 8) {
-  } else if (split)
+  } else if (cs)
+    CHK(launch_ln_bwd_dx_cs(dh2, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, part2, M, d, dp, s));
+  else if (split)
     CHK(launch_ln_bwd_dx(dh2, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, M, d, dp, s));
   else
     CHK(launch_ln_bwd(dh2, a.x_mid, a.mean2, a.rstd2, P(h, p.ln2_g), dx, dx, xmid16, G(h, p.ln2_g),
@@ -1181,6 +1210,8 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
     b.valid = true; b.st = &st; b.l = l; b.M = M; b.q = q;
     b.sr_rows = 0; b.sr_pad = 0;
     b.xin16 = xin16; b.dpre = dpre; b.xmid16 = xmid16; b.dqkv = dqkv; b.dh2 = dh2; b.dh1 = dh1;
+    b.part2 = (h->skip & 8) ? nullptr : part2; b.part1 = (h->skip & 8) ? nullptr : part1;
+    b.part_blocks = ln_cs_blocks(M);
     b.s = s; b.w = w; b.slab = inl ? sc.slab : nullptr;
     if (!h->wgrad_defer) CHK(flush_batch(h, sc));
   }
@@ -1192,7 +1223,9 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   }
   KScope kln1(h, KP_LN_BWD, s, 0, Md * d * 16.0);
   if (h->skip & 8) {
-  } else if (split)
+  } else if (cs)
+    CHK(launch_ln_bwd_dx_cs(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, part1, M, d, dp, s));
+  else if (split)
     CHK(launch_ln_bwd_dx(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, M, d, dp, s));
   else
     CHK(launch_ln_bwd(dh1, a.x_in, a.mean1, a.rstd1, P(h, p.ln1_g), dx, dx, xout16, G(h, p.ln1_g),
@@ -1281,7 +1314,7 @@ int layer_backward_sr(FactHandle* h, Stack& st, int l, int B, int T, float* dx, 
     PendingBatch& b = sc.pend;
     b = PendingBatch();
     b.valid = true; b.st = &st; b.l = l; b.M = M; b.q = q;
-    b.dqkv = dqkv; b.dh1 = dh1;
+    b.dqkv = dqkv; b.dh1 = dh1; b.part2 = nullptr; b.part1 = nullptr;
     b.s = s; b.w = w; b.slab = nullptr;
     b.sr_rows = Mr; b.sr_pad = Kc; b.sr_B = B; b.sr_T = T;
     if (!h->wgrad_defer) CHK(flush_batch(h, sc));
@@ -1657,7 +1690,7 @@ int fact_debug_set_option(FactHandle* h, const char* key, int value) {
     return 0;
   }
   if (!strcmp(key, "lite_stream")) {
-    if (value && !h->lite) HIPCHK(hipStreamCreateWithFlags(&h->lite, hipStreamNonBlocking));
+    if (value == 1 && !h->lite) HIPCHK(hipStreamCreateWithFlags(&h->lite, hipStreamNonBlocking));
     h->use_lite = value;
     return 0;
   }
@@ -1707,6 +1740,11 @@ int fact_debug_set_option(FactHandle* h, const char* key, int value) {
   }
   if (!strcmp(key, "ln_split")) {
     h->ln_split = value;
+    return 0;
+  }
+  if (!strcmp(key, "ln_cs")) {  // 0 = col_tasks pass; 1 = partials from the dx kernel, 4 rows per wave; 2 = 2 rows per wave
+    h->ln_cs = value;
+    if (value) ln_set_cs_rows(value == 2 ? 2 : 4);  // process-wide kernel shape
     return 0;
   }
   if (!strcmp(key, "wgrad_big")) {
@@ -2212,8 +2250,25 @@ int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const floa
     }
     ws = buf;
   }
-  if (g_op_ln_ws == 0 && dgamma && dbeta) {
-    // the engine's form: parameter gradients (here from the fp32 residual gradient, before dx may overwrite it
+  if ((g_op_ln_ws == 3 || g_op_ln_ws == 4) && C <= 1024 && dgamma && dbeta) {
+    // round-4 engine form: the dx kernel leaves per-workgroup column-sum partials, a small reduce adds them up
+    static float* pbuf = nullptr;
+    static size_t pcap = 0;
+    const size_t need = ln_cs_part_floats(M, C);
+    if (need > pcap) {
+      if (pbuf) (void)hipFree(pbuf);
+      if (hipMalloc(&pbuf, need * sizeof(float)) != hipSuccess) return fail(-20, "ln partials alloc");
+      pcap = need;
+    }
+    ln_set_cs_rows(g_op_ln_ws == 4 ? 2 : 4);
+    CHK(launch_ln_bwd_dx_cs((const bf16_t*)dh, x, mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, pbuf, M, C, C,
+                            (hipStream_t)stream));
+    CHK(launch_colreduce(pbuf, ln_cs_blocks(M), C, dgamma, dbeta, (dres ? dbias_prev : nullptr), (hipStream_t)stream));
+    ln_set_cs_rows(4);
+    return 0;
+  }
+  if ((g_op_ln_ws == 0 || g_op_ln_ws >= 3) && dgamma && dbeta) {
+    // the round-2/3 engine form: parameter gradients (here from the fp32 residual gradient, before dx may overwrite it
     // in place), then the row-wise dx kernel
     CHK(launch_ln_param_grads((const bf16_t*)dh, C, x, mean, rstd, (dbias_prev ? dres : nullptr), C, 1, dgamma, dbeta,
                               dbias_prev, M, C, (hipStream_t)stream));

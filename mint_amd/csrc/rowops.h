@@ -29,6 +29,15 @@ int launch_ln_bwd(const bf16_t* dh, const float* x, const float* mean, const flo
 //                           sums only the optimizer needs: the engine queues them on the wgrad stream.
 int launch_ln_bwd_dx(const bf16_t* dh, const float* x, const float* mean, const float* rstd, const float* gamma,
                      const float* dres, float* dx, bf16_t* dx_bf16, int M, int C, int ld16, hipStream_t s);
+// Round 4: the row-wise dx kernel that also leaves the three column sums as per-workgroup partial rows
+// part[ln_cs_blocks(M)][3][C] (dh * xhat, dh, dres); launch_colreduce adds them into dgamma / dbeta / dbias later, off the
+// dgrad chain.  C % 4 == 0, C <= 1024; `part` >= ln_cs_part_floats(M, C) floats.
+int ln_cs_blocks(int M);
+size_t ln_cs_part_floats(int M, int C);
+void ln_set_cs_rows(int rows_per_wave);  // 2 or 4 (default)
+int launch_ln_bwd_dx_cs(const bf16_t* dh, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* dres, float* dx, bf16_t* dx_bf16, float* part, int M, int C, int ld16, hipStream_t s);
+int launch_colreduce(const float* part, int nblk, int C, float* o0, float* o1, float* o2, hipStream_t s);
 int launch_ln_param_grads(const bf16_t* dh, int ld16, const float* x, const float* mean, const float* rstd,
                           const void* dy, int ldy, int dy_is_f32, float* dgamma, float* dbeta, float* dbias, int M,
                           int C, hipStream_t s);

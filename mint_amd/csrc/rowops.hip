@@ -243,6 +243,124 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const bf16_t* __restrict
   }
 }
 
+// ---- round 4: the row-wise dx kernel ALSO produces the column sums only the optimizer reads, as per-workgroup
+// partials.  The split of round 2 kept the dgrad chain short (the old fused kernel above runs 37 us in the step against
+// 22 us: two rows per wave behind each other, 38 KiB of LDS, 2400 atomics per workgroup or a reduce launch ON the chain)
+// but its column-sum pass re-reads dh, x and the entering gradient - 74 MB per layer of the 109 MB col_tasks_kernel
+// moves, 46-50 us per layer on the wgrad stream and HBM traffic beside the GELU' dgrad.  Here a workgroup owns 4 * RPW
+// consecutive rows (a wave RPW of them, two in flight at a time), every lane keeps the three column accumulators of its
+// 4 * MAXV columns in registers while it walks its rows, and at the end the four waves' accumulators meet in LDS and leave
+// as ONE plain-store row part[block][3][C] (no atomics, nothing waits for them).  A tiny reduce over the blocks
+// (colreduce_kernel) runs later on the wgrad stream: 3.5 MB per LayerNorm instead of 37 MB.
+//   part[b][0][c] = sum_rows dh * xhat   part[b][1][c] = sum_rows dh   part[b][2][c] = sum_rows dres (0 without dres)
+template <int MAXV, int RPW>
+__global__ __launch_bounds__(256) void ln_bwd_dx_cs_kernel(const bf16_t* __restrict__ dh, const float* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* dres, float* dx,
+                                                           bf16_t* __restrict__ dx16, float* __restrict__ part, int M, int C,
+                                                           int ld16) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][3][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv = C >> 2;
+  const float invC = 1.0f / (float)C;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ag[MAXV], ab[MAXV], ar[MAXV], gmm[MAXV];
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    ag[i] = z4; ab[i] = z4; ar[i] = z4;
+    const int idx = lane + i * 64;
+    gmm[i] = (idx < nv) ? g4[idx] : z4;
+  }
+  const int row0 = blockIdx.x * (4 * RPW) + wave * RPW;
+  static_assert(RPW % 2 == 0, "rows go through the wave two at a time");
+#pragma unroll 1
+  for (int k0 = 0; k0 < RPW; k0 += 2) {
+    float4 xv[2][MAXV], rv[2][MAXV];
+    bf16x4 dv[2][MAXV];
+    float mu[2], rs[2];
+    // both rows' loads are requested before the first use (a clamped duplicate row past the end is loaded, not used)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = min(row0 + k0 + k, M - 1);
+      mu[k] = mean[row];
+      rs[k] = rstd[row];
+      const float4* xr = reinterpret_cast<const float4*>(x + (size_t)row * C);
+      const bf16x4* dhr = reinterpret_cast<const bf16x4*>(dh + (size_t)row * ld16);
+      const float4* rr4 = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * C) : nullptr;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nv) {
+          xv[k][i] = xr[idx];
+          dv[k][i] = dhr[idx];
+          rv[k][i] = rr4 ? rr4[idx] : z4;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int row = row0 + k0 + k;
+      if (row >= M) break;  // wave-uniform
+      float4 dy[MAXV];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nv) {
+          const float d0 = (float)dv[k][i][0], d1 = (float)dv[k][i][1], d2 = (float)dv[k][i][2], d3 = (float)dv[k][i][3];
+          float4& xh = xv[k][i];
+          xh = make_float4((xh.x - mu[k]) * rs[k], (xh.y - mu[k]) * rs[k], (xh.z - mu[k]) * rs[k], (xh.w - mu[k]) * rs[k]);
+          dy[i] = make_float4(d0 * gmm[i].x, d1 * gmm[i].y, d2 * gmm[i].z, d3 * gmm[i].w);
+          s1 += (dy[i].x + dy[i].y) + (dy[i].z + dy[i].w);
+          s2 += (dy[i].x * xh.x + dy[i].y * xh.y) + (dy[i].z * xh.z + dy[i].w * xh.w);
+          ag[i].x += d0 * xh.x; ag[i].y += d1 * xh.y; ag[i].z += d2 * xh.z; ag[i].w += d3 * xh.w;
+          ab[i].x += d0; ab[i].y += d1; ab[i].z += d2; ab[i].w += d3;
+          const float4 r = rv[k][i];
+          ar[i].x += r.x; ar[i].y += r.y; ar[i].z += r.z; ar[i].w += r.w;
+        }
+      }
+      s1 = wave_sum(s1) * invC;
+      s2 = wave_sum(s2) * invC;
+      float4* dxr = reinterpret_cast<float4*>(dx + (size_t)row * C);
+      bf16x4* dx16r = dx16 ? reinterpret_cast<bf16x4*>(dx16 + (size_t)row * ld16) : nullptr;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int idx = lane + i * 64;
+        if (idx < nv) {
+          const float4 xh = xv[k][i], r = rv[k][i];
+          const float4 o = make_float4(r.x + rs[k] * (dy[i].x - s1 - xh.x * s2), r.y + rs[k] * (dy[i].y - s1 - xh.y * s2),
+                                       r.z + rs[k] * (dy[i].z - s1 - xh.z * s2), r.w + rs[k] * (dy[i].w - s1 - xh.w * s2));
+          dxr[idx] = o;
+          if (dx16r) {
+            bf16x4 o16 = {(bf16_t)o.x, (bf16_t)o.y, (bf16_t)o.z, (bf16_t)o.w};
+            dx16r[idx] = o16;
+          }
+        }
+      }
+    }
+  }
+  // the four waves' column accumulators -> one partial row of this block
+  float4* r4 = reinterpret_cast<float4*>(red);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = lane + i * 64;
+    if (idx < nv) {
+      r4[(wave * 3 + 0) * nv + idx] = ag[i];
+      r4[(wave * 3 + 1) * nv + idx] = ab[i];
+      r4[(wave * 3 + 2) * nv + idx] = ar[i];
+    }
+  }
+  __syncthreads();
+  float4* p4 = reinterpret_cast<float4*>(part + (size_t)blockIdx.x * 3 * C);
+  const int n4 = 3 * nv;
+  for (int j = threadIdx.x; j < n4; j += 256) {
+    const float4 a = r4[j], b = r4[n4 + j], c = r4[2 * n4 + j], d = r4[3 * n4 + j];
+    p4[j] = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z),
+                        (a.w + b.w) + (c.w + d.w));
+  }
+}
+
 // dgamma[c] += sum_r dh[r][c] * xhat[r][c];  dbeta[c] += sum_r dh[r][c];  dbias[c] += sum_r dy[r][c]
 // grid (ceil(C / 256), ceil(M / rows_per_block)), block 256 = 4 waves; a lane owns 4 consecutive columns, the
 // waves of a block interleave the rows of its chunk; one LDS reduction and 3 atomics per column and block.
@@ -1002,6 +1120,34 @@ int launch_ln_bwd_dx(const bf16_t* dh, const float* x, const float* mean, const 
   else
     FACT_LAUNCH((ln_bwd_dx_kernel<8>), dim3(grid), dim3(256), 0, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
                        M, C, ld16);
+  return 0;
+}
+
+int g_ln_cs_rpw = 4;  // rows per wave of ln_bwd_dx_cs_kernel (2 or 4): test / bench knob
+void ln_set_cs_rows(int rpw) { g_ln_cs_rpw = (rpw == 2) ? 2 : 4; }
+int ln_cs_blocks(int M) { return (M + 4 * g_ln_cs_rpw - 1) / (4 * g_ln_cs_rpw); }
+size_t ln_cs_part_floats(int M, int C) { return (size_t)((M + 7) / 8) * 3 * C; }  // sized for 2 rows per wave
+
+int launch_ln_bwd_dx_cs(const bf16_t* dh, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* dres, float* dx, bf16_t* dx_bf16, float* part, int M, int C, int ld16,
+                        hipStream_t s) {
+  if ((C & 3) || C > 1024 || M <= 0 || ld16 < C || (ld16 & 3) || !part) return -1;  // wider rows: the split kernels
+  const int grid = ln_cs_blocks(M);
+  const size_t shmem = (size_t)4 * 3 * C * sizeof(float);
+  if (g_ln_cs_rpw == 2)
+    FACT_LAUNCH((ln_bwd_dx_cs_kernel<4, 2>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
+                part, M, C, ld16);
+  else
+    FACT_LAUNCH((ln_bwd_dx_cs_kernel<4, 4>), dim3(grid), dim3(256), shmem, s, dh, x, mean, rstd, gamma, dres, dx, dx_bf16,
+                part, M, C, ld16);
+  return 0;
+}
+
+// o_k[c] += sum over the nblk partial rows part[b][k][c], k = 0..2 (any o_k may be null)
+int launch_colreduce(const float* part, int nblk, int C, float* o0, float* o1, float* o2, hipStream_t s) {
+  if (nblk <= 0 || C <= 0) return -1;
+  dim3 g2((3 * C + 255) / 256, (nblk + 31) / 32);
+  FACT_LAUNCH(colreduce_kernel, g2, dim3(256), 0, s, part, nblk, C, o0, o1, o2);
   return 0;
 }
 

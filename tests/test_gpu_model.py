@@ -850,3 +850,29 @@ def test_grad_overwrite_off_again_clears_the_overwritten_ranges():
         assert torch.allclose(now[sl], want, rtol=5e-3, atol=1e-6), name
     with pytest.raises(ValueError):
         model.set_option("skip", 1)  # lab-bench knobs are not reachable through the production option call
+
+
+def test_layernorm_partials_path_matches_column_sum_pass(continuous_attention):
+    """Debug option ln_cs (round 4): the row-wise LayerNorm-backward kernel leaves the gamma / beta / bias column sums as
+    per-workgroup partials and a small reduce adds them up, instead of the separate column-sum pass over dh / x / dy.
+    Same sums in another order - and the to_out / dense_2 bias gradients now summed from the fp32 residual gradient rather
+    than from its bf16 copy (the column-sum pass reads xmid16 / xin16): every gradient tensor of one step agrees to fp32
+    round-off, those two to bf16 round-off (also with 2 rows per wave)."""
+    cfg = O.TINY_CFG
+    b = gpu_batch(O.synthetic_batch(cfg, 4, 8, seed=7))
+    inp = {k: v for k, v in b.items() if k != "target"}
+    grads = []
+    for mode in (0, 1, 2):
+        torch.manual_seed(0)
+        model = model_builder.build(make_config(cfg), True)
+        model.build(4, 225, 35)
+        model.debug_option("ln_cs", mode)
+        model.forward_backward(inp, b["target"])
+        torch.cuda.synchronize()
+        grads.append(model.grad_arena.detach().clone())
+    for g in grads[1:]:
+        for name, off, rows, cols, kind in model._table:
+            a, r = g[off:off + rows * cols], grads[0][off:off + rows * cols]
+            bias_of_resid_gemm = name.endswith(("/attn/to_out/bias", "/mlp/dense_2/bias"))
+            tol = 5e-3 if bias_of_resid_gemm else 1e-4
+            assert torch.allclose(a, r, rtol=2e-3, atol=1e-6 + tol * float(r.abs().max())), name

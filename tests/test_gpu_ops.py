@@ -340,10 +340,11 @@ def test_gemm_tn_group_small_dims(tn_group_loop):
 # ------------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[0, 2], ids=["split", "fused"])
+@pytest.fixture(params=[0, 2, 3, 4], ids=["split", "fused", "partials4", "partials2"])
 def ln_bwd_mode(request):
-    """LayerNorm backward as the engine runs it (row-wise dx kernel + column-sum parameter-gradient kernel) and
-    the round-1 fused kernel."""
+    """LayerNorm backward as the engine runs it since round 4 (row-wise dx kernel that also leaves per-workgroup
+    column-sum partials + a small reduce; 4 or 2 rows per wave), the round-2 split (dx kernel + column-sum
+    parameter-gradient kernel) and the round-1 fused kernel."""
     L.lib().fact_debug_ln_bwd(8, request.param)
     yield request.param
     L.lib().fact_debug_ln_bwd(8, 0)
