@@ -94,8 +94,8 @@ N_CUS = 256
 def class_kernels(rec):
     """What the engine's recorder saw behind one class of the table (FACT_LAUNCH notes, fact_kprof_kernels): the symbol
     of the most frequent launch shape exactly as rocprofv3 prints it (the cross-modal layers outnumber the encoder
-    layers 12 : 4, so this is the cross-modal launch), its grid, and the CUs that grid can hold -
-    min(256, ceil(grid / workgroups per CU)) with the runtime's occupancy answer for the launch shape."""
+    layers 12 : 4, so this is the cross-modal launch), its grid, the runtime's occupancy answer for the launch shape
+    (workgroups per CU) and the CUs the launch is spread over, min(256, grid)."""
     ks = rec.get("kernels") or []
     if not ks:
         return {"kernel": rec["name"], "cu_share": None}
@@ -104,8 +104,9 @@ def class_kernels(rec):
     for k in ks:  # distinct symbols of the class, most frequent first (attention backward: dQ and dK/dV kernels)
         if k["name"] not in names:
             names.append(k["name"])
-    per_cu = max(1, top["workgroups_per_cu"])
-    cus = min(N_CUS, -(-top["grid"] // per_cu))
+    # the dispatcher deals the workgroups of a launch round-robin over XCDs and CUs: a grid of G workgroups touches
+    # min(256, G) CUs (a 2-per-CU kernel with 161 workgroups sits half-filled on 161 CUs, it is not packed onto 81)
+    cus = min(N_CUS, top["grid"])
     return {"kernel": " + ".join(names[:2]), "grid": top["grid"], "block": top["block"], "lds_bytes": top["lds_bytes"],
             "workgroups_per_cu": top["workgroups_per_cu"], "cus_held": cus, "cu_share": round(cus / N_CUS, 3)}
 

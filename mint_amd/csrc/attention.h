@@ -30,6 +30,7 @@ struct AttnParams {
   int nq;             // > 0: only query rows t < nq matter (supervised-rows shortcut of the last layer): forward computes
                       // those rows only; backward treats dO rows >= nq as zero (the LDS-resident kernels skip the work,
                       // the other families rely on the caller having zeroed those dO rows)
+  int qblocks;        // filled by the launcher: 128-query blocks per head of the streaming forward's 1-D grid
   unsigned long long* ts;  // bench only: per-wave s_memtime stamps of the resident forward kernel (null = off)
 };
 

@@ -1005,10 +1005,21 @@ __global__ __launch_bounds__(256, DH > 96 ? 2 : 3) void attn_fwd_st_kernel(const
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bh = blockIdx.y;
+  // 1-D grid of (query blocks per head) x (heads), re-dealt so that the query blocks of one head are NEIGHBOURS ON ONE
+  // XCD (block b runs on XCD b % 8, observed): the 2-3 workgroups that stream the same K / V tiles then hit one private L2
+  // instead of pulling them through the fabric once per XCD (round 4: the kernel moves 69 MB of K / V by LDS-DMA for
+  // 23.6 MB of operands - 5.3 TB/s over its loop, the fabric's rate).  Speed only; any placement is correct.
+  int bh, qblk;
+  {
+    const int nwg = gridDim.x, orig = blockIdx.x;
+    const int xcd = orig & 7, per = nwg >> 3, rem = nwg & 7;
+    const int lid = (xcd < rem ? xcd * (per + 1) : rem * (per + 1) + (xcd - rem) * per) + (orig >> 3);
+    bh = lid / p.qblocks;
+    qblk = lid - bh * p.qblocks;
+  }
   const int T = (p.n + 31) >> 5;
   const size_t row_base = (size_t)bh * p.NP * G::DHP;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = qblk * 128 + wave * 32;
   // wave-uniform; inactive waves still stage and synchronise.  Supervised-rows shortcut (nq): only the first nq queries of
   // a sequence are wanted - the launcher sizes the grid for them, waves past them only help with the staging
   const bool active = q0 < ((p.nq > 0 && p.nq < p.n) ? p.nq : p.n);
@@ -1882,7 +1893,8 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
     AttnParams q = p;
     if (!bwd_is_resident<DH>(p.n)) q.nq = 0;
     const int nqv = (q.nq > 0 && q.nq < q.n) ? q.nq : q.n;
-    FACT_LAUNCH(attn_fwd_st_kernel<DH>, dim3((nqv + 127) / 128, q.B * q.H), dim3(256), lds, s, q);
+    q.qblocks = (nqv + 127) / 128;
+    FACT_LAUNCH(attn_fwd_st_kernel<DH>, dim3(q.qblocks * q.B * q.H), dim3(256), lds, s, q);
     return 0;
   }
   const size_t lds = res_lds_bytes<DH>(p.n, 0);

@@ -55,7 +55,7 @@ def test_executed_fraction_of_the_supervised_rows_shortcut(bench):
 
 def test_kernel_name_and_cu_share_come_from_the_engine_record(bench):
     """The `kernel` / `cu_share` of a bench row are derived from what the engine's recorder saw launched (symbol, grid,
-    occupancy), not from a hand-kept table: most frequent launch shape first, CUs held = ceil(grid / workgroups per CU)."""
+    occupancy), not from a hand-kept table: most frequent launch shape first, CUs touched = min(256, grid)."""
     rec = {"name": "attention_bwd", "kernels": [
         {"count": 24, "grid": 160, "block": 768, "lds_bytes": 147456, "workgroups_per_cu": 1, "name": "dq<80, 0>(AttnParams)"},
         {"count": 24, "grid": 160, "block": 512, "lds_bytes": 150528, "workgroups_per_cu": 1, "name": "dkdv<80, 0>(AttnParams)"},
@@ -65,8 +65,8 @@ def test_kernel_name_and_cu_share_come_from_the_engine_record(bench):
     assert ck["cus_held"] == 160 and ck["cu_share"] == 0.625
     two = bench.class_kernels({"name": "out_proj+resid", "kernels": [
         {"count": 12, "grid": 162, "block": 512, "lds_bytes": 73728, "workgroups_per_cu": 2, "name": "big_nt<...>"}]})
-    assert two["cus_held"] == 81
+    assert two["cus_held"] == 162 and two["workgroups_per_cu"] == 2
     full = bench.class_kernels({"name": "ln_fwd", "kernels": [
         {"count": 31, "grid": 1440, "block": 256, "lds_bytes": 0, "workgroups_per_cu": 8, "name": "ln_fwd_kernel<4>"}]})
-    assert full["cus_held"] == 180
+    assert full["cus_held"] == 256
     assert bench.class_kernels({"name": "x", "kernels": []}) == {"kernel": "x", "cu_share": None}
