@@ -1702,6 +1702,10 @@ int fact_debug_set_option(FactHandle* h, const char* key, int value) {
     gemm_set_k64(value);
     return 0;
   }
+  if (!strcmp(key, "tile192")) {  // process-wide: 192x160 tiles for the whole-K N = 800 dgrads
+    gemm_set_tile192(value);
+    return 0;
+  }
   if (!strcmp(key, "skip")) {  // TIMING ONLY: results are wrong while it is set
     h->skip = value;
     return 0;

@@ -210,6 +210,28 @@ def test_gemm_nt_k64_slots(M, N, K, variant):
         lib.fact_debug_gemm_nt_variant(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(5760, 800, 3072), (3840, 800, 2400), (1920, 800, 3072), (577, 260, 192), (192, 160, 64)])
+def test_gemm_nt_tile192(M, N, K):
+    """The 192x160 tile of round 4 (whole-K N = 800 dgrads of the backward chain: 150 tiles at M = 5760 where 256x160 gives
+    115), forced on full, encoder-sized and ragged shapes; bf16 output only - it exists for the dgrad epilogue."""
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(12)
+    ld = (K + 63) // 64 * 64  # 64-deep ring slots read whole 128-byte lines: row pitch = K rounded up (the engine's pitches)
+    A = torch.zeros(M, ld, device=DEV, dtype=torch.bfloat16)
+    B = torch.zeros(N, ld, device=DEV, dtype=torch.bfloat16)
+    A[:, :K] = _bf(torch.randn(M, K, device=DEV, generator=g))
+    B[:, :K] = _bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
+    ref = A[:, :K].float() @ B[:, :K].float().t()
+    lib.fact_debug_gemm_nt_variant(20)
+    try:
+        out = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _gemm_nt(L.EPI_BF16, A, B, M, N, K, out)
+    finally:
+        lib.fact_debug_gemm_nt_variant(0)
+    _close(out, ref, 1e-2, 1e-2 * math.sqrt(K) * 0.1, "gemm_nt 192x160")
+    assert _rel_err(out, ref) < 4e-3
+
+
 def test_gemm_nt_epilogues(nt_variant):
     M, N, K, seq = 480, 800, 256, 120
     g = torch.Generator(device=DEV).manual_seed(2)

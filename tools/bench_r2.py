@@ -147,6 +147,11 @@ if __name__ == "__main__":
             nt_case(Me, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 12], "enc out-proj")
             nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [1, 10, 11, 14], "enc FFN1")
         nt_case(8192, 8192, 8192, L.EPI_BF16, [1, 7, 11], "8192^3")
+    if what == "t192":  # whole-K N = 800 dgrads: 256x160 (v117: 64-deep, no split-K) vs 192x160 (v20), alone on the chip
+        for rep in range(2):
+            for Me in (5760, 3840, 1920):
+                nt_case(Me, 800, 3072, L.EPI_BF16, [117, 20], "dgrad FFN1")
+                nt_case(Me, 800, 2400, L.EPI_BF16, [117, 20], "dgrad QKV")
     if what == "small":
         for Me in (5760, 3840, 1920):
             nt_case(Me, 800, 800, L.EPI_BF16, [1, 112, 14], "N800 K800 bf16")
