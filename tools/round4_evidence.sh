@@ -23,6 +23,7 @@ if has pmc; then
   python $R/tools/step_pmc.py $O/step_pmc.txt $dirs --traffic-json $O/roofline_traffic.json | head -16; rm -rf $dirs
 fi
 if has standalone; then
+  [ -x $R/tools/bin/mfma_rate_probe ] || (mkdir -p $R/tools/bin && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result $R/tools/mfma_rate_probe.hip -o $R/tools/bin/mfma_rate_probe)
   (cd $R && { timeout 300 python tools/bench_r2.py nt; timeout 200 python tools/bench_r2.py k64; TN_LOOPS=0,2 timeout 200 python tools/bench_r2.py tn; timeout 200 python tools/rowops_bench.py; $R/tools/bin/mfma_rate_probe; } > $O/standalone.txt 2>&1; grep -v amdgpu.ids $O/standalone.txt | head -40)
 fi
 if has attn; then
