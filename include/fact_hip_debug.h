@@ -95,7 +95,7 @@ int fact_debug_gemm_nt_band(int band);
 /* Test/bench knob of fact_op_ln_bwd: LayerNorm-backward rows per workgroup of the round-1 fused kernel (multiple of 4,
  * >= 8); use_ws: 0 = round-2 split (column-sum kernel + row-wise dx kernel), 1 / 2 = round-1 fused kernel with the
  * partial-sum workspace / with atomics, 3 / 4 = round-4 engine form (dx kernel leaving per-workgroup column-sum
- * partials, 4 / 2 rows per wave, + reduce). */
+ * partials, 4 / 2 rows per wave, + reduce), 5 = the row-wise dx kernel alone (bench). */
 int fact_debug_ln_bwd(int rows_per_block, int use_ws);
 
 #ifdef __cplusplus

@@ -2271,6 +2271,10 @@ int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const floa
     ln_set_cs_rows(4);
     return 0;
   }
+  if (g_op_ln_ws == 5) {  // bench: the row-wise dx kernel alone
+    CHK(launch_ln_bwd_dx((const bf16_t*)dh, x, mean, rstd, gamma, dres, dx, (bf16_t*)dx_bf16, M, C, C, (hipStream_t)stream));
+    return 0;
+  }
   if ((g_op_ln_ws == 0 || g_op_ln_ws >= 3) && dgamma && dbeta) {
     // the round-2/3 engine form: parameter gradients (here from the fp32 residual gradient, before dx may overwrite it
     // in place), then the row-wise dx kernel

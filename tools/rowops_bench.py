@@ -36,6 +36,10 @@ for M in (5760, 3840, 1920):
             lib.fact_debug_ln_bwd(rows, ws)
             us = timeit(lambda: L.check(lib.fact_op_ln_bwd(L.ptr(dh), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(dx16), L.ptr(dg), L.ptr(db), L.ptr(dbp), M, C, L.cur_stream())))
             print("ln_bwd M%d rows %d ws %d: %.1f us (%.0f GB/s)" % (M, rows, ws, us, M * C * 18 / us / 1e3))
+    for mode, name in ((5, "dx kernel alone"), (3, "dx + partials (4 rows/wave) + reduce")):
+        lib.fact_debug_ln_bwd(8, mode)
+        us = timeit(lambda: L.check(lib.fact_op_ln_bwd(L.ptr(dh), L.ptr(x), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(dres), L.ptr(dx), L.ptr(dx16), L.ptr(dg), L.ptr(db), L.ptr(dbp), M, C, L.cur_stream())))
+        print("ln_bwd M%d %s: %.1f us (%.0f GB/s)" % (M, name, us, M * C * 16 / us / 1e3))
     lib.fact_debug_ln_bwd(8, 0)
 n = 120406977 // 4 * 4
 p, m, v, g = (torch.randn(n, device=dev) for _ in range(4))
