@@ -1643,6 +1643,7 @@ int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* com
 // arenas - they are cleared, otherwise the next fact_forward_backward would add a fresh gradient to a stale one.
 static int zero_overwritten_grads(FactHandle* h) {
   if (!h->training || !h->grads) return 0;
+  HIPCHK(hipDeviceSynchronize());  // rare host-side switch: nothing of an earlier step may still be writing the arena
   for (Stack* st : {&h->cross, &h->motion, &h->audio})
     for (const LayerP& p : st->lp)
       for (const DenseW* w : {&p.wqkv, &p.wo, &p.w1, &p.w2})
@@ -1985,8 +1986,8 @@ int fact_kprof(FactHandle* h, int on) {
 /* The kernels behind one class of the table, as the recorder saw them launched (FACT_LAUNCH): one text line per distinct
  * (kernel, grid, block, dynamic LDS), most frequent first:
  *   count \t grid \t block \t lds_bytes \t workgroups_per_cu \t demangled kernel name
- * workgroups_per_cu is the runtime's occupancy answer for that launch shape, so min(256, ceil(grid / wgs_per_cu)) is the
- * number of CUs the launch can hold.  Names are what rocprofv3 prints for the same dispatches. */
+ * workgroups_per_cu is the runtime's occupancy answer for that launch shape (how many such workgroups fit one CU); the
+ * dispatcher spreads a launch over min(256, grid) CUs.  Names are what rocprofv3 prints for the same dispatches. */
 int fact_kprof_kernels(FactHandle* h, int cls, char* buf, int cap) {
   if (!h || !buf || cap <= 0) return fail(-1, "null argument");
   if (cls < 0 || cls >= KP_N) return fail(-1, "no such kernel class");
