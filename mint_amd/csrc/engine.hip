@@ -2249,7 +2249,7 @@ int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const floa
     static size_t cap = 0;
     const size_t need = ln_bwd_ws_floats(M, C);
     if (need > cap) {
-      if (buf) hipFree(buf);
+      if (buf) (void)hipFree(buf);
       if (hipMalloc(&buf, need * sizeof(float)) != hipSuccess) return fail(-20, "ln ws alloc");
       cap = need;
     }
