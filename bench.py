@@ -27,6 +27,60 @@ import os
 import sys
 import time
 
+
+
+def launcher_argv(gpus, script, script_args, port, python=None):
+    """argv that starts `gpus` ranks of this script on ONE node, one process per GPU (what the driver types for N > 1):
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ..."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), script] + list(script_args)
+
+
+def requested_gpus(argv):
+    """--gpus N / --gpus=N from a raw argv (read before argparse and before torch is imported); 1 when absent."""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    return n
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def maybe_spawn_ranks(argv=None, environ=None, execve=None):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): become the launcher - re-exec
+    under torch.distributed.run with N ranks (reference: trainer.py:125-135,146-147 builds a MirroredStrategy over all
+    visible GPUs from ONE command).  Under a launcher (WORLD_SIZE set) this is a no-op; main() then checks
+    WORLD_SIZE == --gpus.  Returns the argv it would exec (tests pass `execve` to capture it)."""
+    argv = sys.argv if argv is None else argv
+    environ = os.environ if environ is None else environ
+    n = requested_gpus(argv[1:])
+    if n <= 1 or "WORLD_SIZE" in environ:
+        return None
+    env = dict(environ)
+    env.setdefault("GPU_MAX_HW_QUEUES", "7")          # see below: must be in the ranks' environment before HIP starts
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this driver)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = launcher_argv(n, os.path.abspath(argv[0]), argv[1:], free_port())
+    (execve or os.execve)(cmd[0], cmd, env)
+    return cmd
+
+
+if __name__ == "__main__":
+    maybe_spawn_ranks()
+
+# bench.py reads the in-step kernel-class recorder and takes --opt A/B knobs: it binds the test / bench build of the library
+# (libfact_hip_dbg.so = the production objects + include/fact_hip_debug.h; mint_amd/_lib.py).  FACT_DEBUG_ABI=0 in the
+# environment runs the timed region on the production library instead (no `kernels` / `roofline` objects then).
+os.environ.setdefault("FACT_DEBUG_ABI", "1")
+
 # Data-parallel runs add a communication stream and RCCL's own to the engine's three: with HIP's default of 4
 # hardware queues some of them share a queue and serialise (one-GPU dry run with RCCL initialised, tools/attic/dp_probe.py:
 # 11.4 ms per step at 4 queues, 8.2 at 7, 16.5 at 8).  Must be set before the HIP runtime starts.
@@ -137,6 +191,8 @@ def kernel_table(model, step_fn, nsteps):
             tf = r["flops"] / (r["total_ms"] * 1e-3) / 1e12
             row.update(bound="mfma", achieved=round(tf, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                        frac=round(tf / PEAK_BF16_TFLOPS, 4), flop_per_launch=r["flops"] / r["launches"])
+            if r["bytes"] > 0:  # wgrad launches that carry the optimizer step of their tensors in the epilogue
+                row["fused_optimizer_bytes_per_launch"] = r["bytes"] / r["launches"]
             if ck.get("cu_share"):
                 # the whole-chip `frac` of a class that is deliberately given part of the chip understates the kernel:
                 # frac_of_held_cus = frac / cu_share is the per-CU figure
@@ -525,6 +581,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N does it "
+                         "itself; under torch.distributed.run pass the same N)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     dry = args.dist_backend == "gloo"
@@ -540,6 +599,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     if args.mode in ("ar", "scaled"):
         (run_ar if args.mode == "ar" else run_scaled)(args, device, world, rank, dry)
@@ -587,7 +647,11 @@ def main():
             ev[0].elapsed_time(ev[1]) / 5, ev[1].elapsed_time(ev[2]) / 5, ev[2].elapsed_time(ev[3]) / 5),
             file=sys.stderr)
 
-    rows, ksum_ms = kernel_table(model, lambda: trainer.train_step(it), max(1, args.profile_steps))
+    from mint_amd import _lib as L
+    if L.DEBUG_ABI or hasattr(L.lib(), "fact_kprof"):
+        rows, ksum_ms = kernel_table(model, lambda: trainer.train_step(it), max(1, args.profile_steps))
+    else:  # FACT_DEBUG_ABI=0: timed on the production library, which has no recorder
+        rows, ksum_ms = None, 0.0
     comm = comm_record(trainer, it, args, world)
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -611,11 +675,17 @@ def main():
             "step_mfma_frac": round(frames_per_s * FLOP_PER_FRAME * executed_flop_fraction() / 1e12
                                     / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
+            "library": os.path.basename(L.LIB_PATH),
         }
         if comm is not None:
             out["comm"] = comm
         if dry:
             out["dry_run"] = "gloo, ranks sharing devices: control-flow check of the N > 1 path, not a measurement"
+        if rows is None:  # production library: the headline numbers only
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+            print(json.dumps(out))
+    if rank == 0 and rows is not None:
         out["kernels"] = rows
         top = rows[0]
         traffic, src = measured_traffic(top["name"])

@@ -20,8 +20,17 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libfact_hip.so is built with -fvisibility=hidden: the entry points declared in this header are the library's whole
+ * exported surface (tests/test_cabi.py compares `nm -D` with this file). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define FACT_ABI_VERSION 1
+/* 2 (rounds 4-5): the A/B and ablation option keys, the recorder, single-op and probe entry points moved to
+ * fact_hip_debug.h (fact_set_option rejects them); fact_create zeroes a caller-provided gradient arena; fact_loss added;
+ * option "adam_in_wgrad" added (when set, a fused step under "grad_overwrite" no longer writes the gradient-arena ranges
+ * of the transformer-layer Dense kernels).  A host built against version 1 must be re-read against this header. */
+#define FACT_ABI_VERSION 2
 
 /* One transformer stack (mint/core/base_models.py:91-110) plus the modality it embeds. */
 typedef struct FactStackCfg {
@@ -176,11 +185,25 @@ int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* com
  *                        handle starts at 0 with a zeroed gradient arena (caller-provided arenas included), and setting
  *                        it back to 0 clears the ranges that were being overwritten, so accumulation never starts on
  *                        a stale gradient.
+ *   "adam_in_wgrad"  (default 0) 1 = in the engine-owned fused step (fact_adam_begin + fact_forward_backward, no gradient
+ *                        callback) with "grad_overwrite" on, the Adam update and bf16-shadow refresh of every
+ *                        transformer-layer Dense kernel run in the epilogue of the whole-K grouped wgrad launch that
+ *                        holds its finished gradient in registers (28 bytes per parameter instead of 4 + 32; the
+ *                        optimizer pass shrinks to biases, LayerNorm, position tables, embedding / head kernels).  The
+ *                        gradient-arena ranges of those kernels are then NOT written by the step.  Same arithmetic as
+ *                        the optimizer pass (Keras Adam, single_task_trainer.py:186-187 / trainer.py:150); takes effect
+ *                        only when every stack runs the grouped launch (B * seq_len a multiple of 32 and >= 512, widths
+ *                        multiples of 16), otherwise the step silently keeps the bucket path.  0 = always the bucket path.
+ *                        Pays when the wgrad launches fill the chip; at fact_v5 / batch 16 they are given 95 of 256 CUs
+ *                        beside the dgrad chain and the update streams at what 95 CUs can pull.
  *   "side_stream"    (default 1) 1 = the weight-gradient batches / the audio encoder run on the handle's second stream
  *   "aux_stream"     (default 1) 1 = the motion encoder's backward chain runs on the handle's third stream; hosts that
  *                        add a communication stream (data parallelism) set 0 to stay within the hardware queues */
 int fact_set_option(FactHandle* h, const char* key, int value);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -10,6 +10,16 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* Exported only by the test / bench build of the library (mint_amd/lib/libfact_hip_dbg.so: engine.hip and probe.hip
+ * compiled with -DFACT_DEBUG_ABI).  In the production libfact_hip.so these functions are compiled with hidden visibility:
+ * `dlsym(lib, "fact_debug_set_option")` finds nothing there. */
+#if defined(__GNUC__) || defined(__clang__)
+#ifdef FACT_DEBUG_ABI
+#pragma GCC visibility push(default)
+#else
+#pragma GCC visibility push(hidden)
+#endif
+#endif
 
 /* In-step kernel-class timing.  fact_kprof(h, 1) arms it (and clears earlier records): every instrumented launch
  * site of the following forward / backward calls is bracketed by HIP events recorded on the stream it launches
@@ -53,6 +63,15 @@ int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int 
 int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                           float* const* out, const int* ldo, const int* Mo, const int* No, const int* trans, int K,
                           void* stream);
+/* The same launch with the optimizer in its epilogue (engine option "adam_in_wgrad", gemm.h TnGroup::adam): problem i
+ * updates p_i / m_i / v_i (fp32, indexed like out_i would be: [Mo_i][No_i], or [No_i][Mo_i] when trans[i]) with Keras Adam
+ * on the gradient A_i^T B_i and writes the bf16 shadows s_i (same orientation, row pitch lds_i) and t_i (transposed, row
+ * pitch ldt_i).  Mo, No % 16 == 0.  Replaces, for the layer kernels, the tape's gradient + optimizer.apply_gradients
+ * (single_task_trainer.py:175-187). */
+int fact_op_gemm_tn_group_adam(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                               float* const* p, float* const* m, float* const* v, void* const* s, const int* lds,
+                               void* const* t, const int* ldt, const int* Mo, const int* No, const int* trans, int K,
+                               float lr_t, float beta1, float beta2, float eps, void* stream);
 int fact_op_ln_fwd(const float* x, const float* gamma, const float* beta, void* h, float* mean,
                    float* rstd, int M, int C, float eps, void* stream);
 int fact_op_ln_bwd(const void* dh, const float* x, const float* mean, const float* rstd,
@@ -98,6 +117,9 @@ int fact_debug_gemm_nt_band(int band);
  * partials, 4 / 2 rows per wave, + reduce), 5 = the row-wise dx kernel alone (bench). */
 int fact_debug_ln_bwd(int rows_per_block, int use_ws);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -9,9 +9,17 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# FACT_LIB: a development build of the SAME library (tools/build_variant.sh, same-box A/B of kernel variants); the shipped
-# in-tree library otherwise.  Either way a missing file is an error, never a fallback.
-LIB_PATH = os.environ.get("FACT_LIB") or os.path.join(_HERE, "lib", "libfact_hip.so")
+# Two builds of the same objects (mint_amd/csrc/build.sh):
+#   libfact_hip.so      the production library - exports include/fact_hip.h and nothing else (-fvisibility=hidden)
+#   libfact_hip_dbg.so  engine.hip / probe.hip compiled -DFACT_DEBUG_ABI: additionally exports include/fact_hip_debug.h
+# A process binds ONE of them (kernel-selection knobs are process-wide state of the library): FACT_DEBUG_ABI=1 in the
+# environment before this module is imported selects the test / bench build (tests/conftest.py and bench.py set it).
+# FACT_LIB: a development build of the library (tools/build_variant.sh, same-box A/B of kernel variants).  A missing file is
+# an error, never a fallback.
+DEBUG_ABI = os.environ.get("FACT_DEBUG_ABI", "0") not in ("", "0")
+PROD_LIB_PATH = os.path.join(_HERE, "lib", "libfact_hip.so")
+DEBUG_LIB_PATH = os.path.join(_HERE, "lib", "libfact_hip_dbg.so")
+LIB_PATH = os.environ.get("FACT_LIB") or (DEBUG_LIB_PATH if DEBUG_ABI else PROD_LIB_PATH)
 
 # epilogue kinds (mint_amd/csrc/gemm.h)
 EPI_BF16, EPI_F32_BIAS, EPI_F32_BIAS_POS, EPI_F32_BIAS_RESID = 0, 1, 2, 3
@@ -80,6 +88,9 @@ SIGNATURES = {
     "fact_op_gemm_tn": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "fact_op_gemm_tn_group": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp),
                                    C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
+    "fact_op_gemm_tn_group_adam": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp),
+                                        C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp),
+                                        C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _f, _f, _f, _f, _vp]),
     "fact_op_ln_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "fact_op_ln_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "fact_op_attention_scratch": (_sz, [_i, _i, _i, _i]),
@@ -105,7 +116,7 @@ SIGNATURES = {
 # declared in include/fact_hip_debug.h (everything else: include/fact_hip.h, the drop-in boundary)
 DEBUG_SYMBOLS = frozenset(n for n in SIGNATURES if n.startswith(("fact_debug_", "fact_op_", "fact_probe_", "fact_kprof")))
 # keys fact_set_option accepts; every other engine knob goes through fact_debug_set_option
-PUBLIC_OPTIONS = ("sr_rows", "grad_overwrite", "side_stream", "aux_stream")
+PUBLIC_OPTIONS = ("sr_rows", "grad_overwrite", "adam_in_wgrad", "side_stream", "aux_stream")
 
 _LIB = None
 
@@ -129,11 +140,23 @@ def lib():
         import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                if name in DEBUG_SYMBOLS and not DEBUG_ABI:
+                    continue  # the production library does not export the test / bench surface
+                raise
             fn.restype = res
             fn.argtypes = args
         _LIB = l
     return _LIB
+
+
+def need_debug_abi(what):
+    """Raise a readable error when a test / bench entry point is asked of the production library."""
+    if not hasattr(lib(), "fact_debug_set_option"):
+        raise RuntimeError("%s needs the test / bench build of the library: set FACT_DEBUG_ABI=1 before importing mint_amd "
+                           "(libfact_hip_dbg.so; the production libfact_hip.so exports include/fact_hip.h only)" % what)
 
 
 def check(rc):

@@ -1605,7 +1605,12 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_r2_kernel(const AttnParams p)
 
   const float sc = p.scale * LOG2E;
   const int nkt = rows >> 5;
-  auto body = [&](auto jc) {
+  // Padded keys (n % 32 != 0: the last key tile only).  Their K / V rows are zero rows, so the score is 0 and
+  // P = exp2(-L2[q]) - finite for any realistic row, but +inf once L2[q] < -128, and inf * (0 - D) would reach dQ as
+  // NaN through the dS . K product.  The one tile that holds them zeroes those dS entries by SELECT (wave-uniform
+  // branch, one tile per head: free), which is what the masked round-2/3 kernels did for every score.
+  const int padk_tile = (p.n & 31) ? nkt - 1 : -1;
+  auto body = [&](auto jc, int kt) {
     constexpr int J = decltype(jc)::value;
     f32x4 s[2][2], dp[2][2];
 #pragma unroll
@@ -1634,7 +1639,15 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_r2_kernel(const AttnParams p)
       f32x4 p0, p1;
       r2_p<PK>(s[0][qs], sc, nl, p0);
       r2_p<PK>(s[1][qs], sc, nl, p1);
-      dsb[qs] = pack8(r2_mul<PK>(p0, dp[0][qs]), r2_mul<PK>(p1, dp[1][qs]));
+      f32x4 d0 = r2_mul<PK>(p0, dp[0][qs]), d1 = r2_mul<PK>(p1, dp[1][qs]);
+      if (kt == padk_tile) {  // S^T layout: this lane's 4 scores of sub-tile ks are keys tile * 32 + ks * 16 + g * 4 + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kt * 32 + g * 4 + r >= p.n) d0[r] = 0.f;
+          if (kt * 32 + 16 + g * 4 + r >= p.n) d1[r] = 0.f;
+        }
+      }
+      dsb[qs] = pack8(d0, d1);
     }
 #pragma unroll
     for (int dt = 0; dt < G::ND; ++dt) {
@@ -1644,10 +1657,10 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_r2_kernel(const AttnParams p)
     }
   };
   for (int kt = 0; kt < nkt; kt += 4) {
-    body(SlotK<0>{});
-    if (kt + 1 < nkt) body(SlotK<1>{});
-    if (kt + 2 < nkt) body(SlotK<2>{});
-    if (kt + 3 < nkt) body(SlotK<3>{});
+    body(SlotK<0>{}, kt);
+    if (kt + 1 < nkt) body(SlotK<1>{}, kt + 1);
+    if (kt + 2 < nkt) body(SlotK<2>{}, kt + 2);
+    if (kt + 3 < nkt) body(SlotK<3>{}, kt + 3);
     kr += 4 * R::TILE; vr += 4 * R::TILE; ke += 4 * R::TILE; ko += 4 * R::TILE;
   }
 #pragma unroll

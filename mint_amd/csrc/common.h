@@ -66,11 +66,20 @@ DEVINL float gelu_tanh_grad(float x) {
   return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * du;
 }
 
+// Keras Adam, one element (optimizer_v2/adam.py _resource_apply_dense, non-amsgrad): lr_t carries both bias corrections,
+// epsilon is added OUTSIDE them.  One definition for the optimizer pass (rowops.hip) and the fused epilogue of the grouped
+// wgrad kernel (gemm_big.hip), so the two paths round identically.
+DEVINL void adam1(float& p, float& m, float& v, float g, float lr_t, float b1, float b2, float eps) {
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  p -= lr_t * m / (sqrtf(v) + eps);
+}
+
 // Every kernel launch of the library goes through FACT_LAUNCH.  While the in-step kernel-class recorder is armed
 // (fact_kprof, engine.hip) the launch is also noted - host function, grid, block, dynamic LDS - so that the bench line can
 // name the kernel symbol that really ran and the CUs its grid can hold, instead of a hand-kept table.  One predictable
 // branch otherwise.
-extern bool g_fact_note_on;
+extern thread_local bool g_fact_note_on;  // true only on a thread that has a recorder scope of an armed handle open
 void fact_note_launch(const void* host_fn, dim3 grid, dim3 block, size_t lds_bytes);
 #define FACT_LAUNCH(kernel, grid, block, lds, stream, ...)                                                    \
   do {                                                                                                          \

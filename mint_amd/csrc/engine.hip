@@ -109,6 +109,10 @@ struct Bucket {
   size_t off = 0, cnt = 0;  // float range in the arenas
   int desc_first = 0, desc_n = 0, tiles = 0;
   int blk_first = 0, blk_n = 0;  // AdamBlock range of the fused optimizer + shadow-refresh kernel
+  // the same range WITHOUT the Dense kernels of transformer layers (their update runs in the epilogue of the grouped wgrad
+  // launch when FactHandle::wg_adam is set): biases, LayerNorm, position tables, embedding / head kernels
+  int lite_first = 0, lite_n = 0;
+  size_t lite_floats = 0;
 };
 struct AdamArgs {
   float lr_t = 0.f, b1 = 0.9f, b2 = 0.999f, eps = 1e-7f, gscale = 1.f;
@@ -292,6 +296,12 @@ struct FactHandle {
                               // re-runs its own forward (there is no split forward / backward entry point)
   bool keep_pre_infer = false;  // what the inference entry points set keep_pre to (read FACT_KEEP_PRE once, at fact_create)
   int adam_hold = 1;          // in-backward optimizer: hold the head + cross buckets until the last is final
+  int adam_in_wgrad = 0;      // (round 5; off by default - measured slower at fact_v5 / B = 16) with fact_adam_begin pending, no gradient callback and grad_overwrite on, the Adam
+                              // update + shadow refresh of every transformer-layer Dense kernel runs in the epilogue of the
+                              // grouped whole-K wgrad launch that produced its gradient (gemm.h TnGroup::adam): 28 instead of
+                              // 4 + 32 bytes per parameter, and the optimizer pass shrinks to the ~0.7 M parameters that are
+                              // not layer kernels.  The gradient arena ranges of those kernels are then not written.
+  bool wg_adam = false;       // this fact_forward_backward call runs that way (decided per call: wg_adam_ok)
   // gradient-bucket-ready callback (data-parallel overlap of the RCCL all-reduce with backward)
   fact_grad_cb cb = nullptr;
   void* cb_user = nullptr;
@@ -302,10 +312,16 @@ struct FactHandle {
 namespace {
 
 }  // namespace
-bool g_fact_note_on = false;
-static std::vector<KNote> g_fact_notes;  // launches since the innermost KScope opened (host enqueue is single-threaded)
+// Launch notes of the recorder.  Both are PER THREAD: a launch is noted only by the thread that has a KScope of an armed
+// handle open (a data-parallel communication thread, or a second model driven from another thread, never writes into
+// this thread's buffer), and only while that scope is open - launches outside any scope are not collected, so the buffer
+// is bounded by the launches of one scope (hard cap below).
+thread_local bool g_fact_note_on = false;
+static thread_local std::vector<KNote> g_fact_notes;
+static constexpr size_t kMaxNotesPerScope = 256;
 void fact_note_launch(const void* host_fn, dim3 grid, dim3 block, size_t lds_bytes) {
-  g_fact_notes.push_back(KNote{host_fn, grid.x * grid.y * grid.z, block.x * block.y * block.z, lds_bytes});
+  if (g_fact_notes.size() < kMaxNotesPerScope)
+    g_fact_notes.push_back(KNote{host_fn, grid.x * grid.y * grid.z, block.x * block.y * block.z, lds_bytes});
 }
 namespace {
 
@@ -313,8 +329,12 @@ struct KScope {
   FactHandle* h;
   hipStream_t s;
   size_t idx = (size_t)-1;
+  bool outer_on = false;              // a scope opened inside another one (none today) hands the notes collected so far
+  std::vector<KNote> outer_notes;     //   back to the outer scope when it closes
   KScope(FactHandle* h_, int cls, hipStream_t s_, double flops, double bytes = 0, int launches = 1) : h(h_), s(s_) {
     if (!h->kp.on) return;
+    outer_on = g_fact_note_on;
+    if (outer_on) outer_notes.swap(g_fact_notes);
     KProf::Rec r;
     r.cls = cls; r.launches = launches; r.flops = flops; r.bytes = bytes;
     r.sid = (s == h->side) ? 1 : (s == h->aux) ? 2 : (s == h->opt) ? 3 : (s == h->lite) ? 4 : 0;
@@ -324,12 +344,15 @@ struct KScope {
     idx = h->kp.recs.size();
     h->kp.recs.push_back(r);
     g_fact_notes.clear();
+    g_fact_note_on = true;
   }
   ~KScope() {
     if (idx == (size_t)-1) return;
     (void)hipEventRecord(h->kp.recs[idx].b, s);
     h->kp.recs[idx].notes.swap(g_fact_notes);
     g_fact_notes.clear();
+    g_fact_note_on = outer_on;
+    if (outer_on) g_fact_notes.swap(outer_notes);
   }
 };
 
@@ -568,8 +591,7 @@ void layout_work(FactHandle* h, Bump& b) {
         sc.xb_pp[q] = b.take<bf16_t>(Mx * dp);
         sc.dh2_pp[q] = b.take<bf16_t>(Mx * dp);
         sc.dh1_pp[q] = b.take<bf16_t>(Mx * dp);
-        sc.lnpart_pp[q][0] = b.take<float>(ln_cs_part_floats((int)Mx, d));
-        sc.lnpart_pp[q][1] = b.take<float>(ln_cs_part_floats((int)Mx, d));
+        // (lnpart_pp: the ln_cs partial buffers are allocated when that debug option is first switched on - alloc_ln_cs)
       }
       sc.dorow = b.take<bf16_t>(rows);
       sc.dsum = b.take<float>(lse);
@@ -645,7 +667,7 @@ int build_buckets(FactHandle* h) {
   HIPCHK(hipMemcpy(h->cast_table, t.data(), t.size() * sizeof(CastDesc), hipMemcpyHostToDevice));
   // Fused Adam + shadow refresh: walk every bucket's arena range; Dense kernels become 64x64 tile
   // blocks, everything between them (biases, LayerNorm, position tables, alignment padding) flat blocks.
-  std::vector<AdamBlock> ab;
+  std::vector<AdamBlock> ab, lite;
   // Dense kernels of transformer layers: their gradient is written (not accumulated) in overwrite mode
   std::vector<size_t> layer_w;
   for (Stack* st : {&h->cross, &h->audio, &h->motion})
@@ -653,6 +675,8 @@ int build_buckets(FactHandle* h) {
       for (DenseW* w : {&p.wqkv, &p.wo, &p.w1, &p.w2}) layer_w.push_back(w->w.off);
   for (Bucket& b : h->buckets) {
     b.blk_first = (int)ab.size();
+    b.lite_first = (int)lite.size();
+    b.lite_floats = 0;
     std::vector<CastDesc> ds(t.begin() + b.desc_first, t.begin() + b.desc_first + b.desc_n);
     std::sort(ds.begin(), ds.end(), [](const CastDesc& x, const CastDesc& y) { return x.src < y.src; });
     size_t cur = b.off;
@@ -663,6 +687,8 @@ int build_buckets(FactHandle* h) {
         k.off = o;
         k.C = (int)std::min<size_t>(4096, end - o);
         ab.push_back(k);
+        lite.push_back(k);
+        b.lite_floats += (size_t)k.C;
       }
     };
     for (const CastDesc& d : ds) {
@@ -677,6 +703,10 @@ int build_buckets(FactHandle* h) {
           k.r0 = r0; k.c0 = c0;
           k.pad[0] = std::find(layer_w.begin(), layer_w.end(), toff) != layer_w.end() ? 1 : 0;
           ab.push_back(k);
+          if (!k.pad[0]) {
+            lite.push_back(k);
+            b.lite_floats += (size_t)std::min(64, d.R - r0) * (size_t)std::min(tw, d.C - c0);
+          }
         }
       // the tail of a Dense tensor whose size is not a multiple of 4 floats is covered by its tile
       // blocks; flat segments resume at the next 64-float boundary (tensor offsets are 64-aligned)
@@ -684,9 +714,30 @@ int build_buckets(FactHandle* h) {
     }
     if (b.off + b.cnt > cur) flat(cur, b.off + b.cnt);
     b.blk_n = (int)ab.size() - b.blk_first;
+    b.lite_n = (int)lite.size() - b.lite_first;
   }
+  // one device table: the full block list, then the lite list
+  const size_t n_full = ab.size();
+  for (Bucket& b : h->buckets) b.lite_first += (int)n_full;
+  ab.insert(ab.end(), lite.begin(), lite.end());
   HIPCHK(hipMalloc((void**)&h->adam_blocks, ab.size() * sizeof(AdamBlock)));
   HIPCHK(hipMemcpy(h->adam_blocks, ab.data(), ab.size() * sizeof(AdamBlock), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// ln_cs (debug option, off by default): per-workgroup column-sum partials of the two LayerNorm backward kernels, three
+// layer parities per backward chain.  ~6 x 7 MB per chain at fact_v5 / B = 16 and ~6 x 26 MB at the scaled configuration:
+// allocated the first time the option is switched on instead of being carved out of every training handle's work arena.
+int alloc_ln_cs(FactHandle* h) {
+  if (!h->training) return 0;
+  const int B = h->max_batch, d = h->cross.d;
+  for (int c = 0; c < 2; ++c) {
+    const int Mx = B * (c ? h->motion.n : h->cross.n);
+    for (int q = 0; q < kBwBuf; ++q)
+      for (int i = 0; i < 2; ++i)
+        if (!h->bw[c].lnpart_pp[q][i])
+          HIPCHK(hipMalloc((void**)&h->bw[c].lnpart_pp[q][i], ln_cs_part_floats(Mx, d) * sizeof(float)));
+  }
   return 0;
 }
 
@@ -704,6 +755,13 @@ int refresh_all(FactHandle* h, hipStream_t s) {
 int adam_bucket(FactHandle* h, int b, hipStream_t s, const bf16_t* g16 = nullptr) {
   const Bucket& k = h->buckets[b];
   const AdamArgs& a = h->adam;
+  if (h->wg_adam) {  // the layer kernels of this bucket were updated by their wgrad launches: what is left of it
+    if (g16 || !h->fuse_adam_cast) return fail(-1, "optimizer fused into the wgrad launches: fp32 buckets, fused Adam kernel");
+    if (!k.lite_n) return 0;
+    KScope ks(h, KP_ADAM, s, 0, (double)k.lite_floats * 36.0);
+    return launch_adam_fused(h->adam_blocks + k.lite_first, k.lite_n, h->params, h->adam_m, h->adam_v, h->grads,
+                             a.lr_t, a.b1, a.b2, a.eps, a.gscale, s, nullptr, h->grad_overwrite);
+  }
   KScope ks(h, KP_ADAM, s, 0, (double)k.cnt * (g16 ? 34.0 : 36.0));
   if (h->fuse_adam_cast)
     return launch_adam_fused(h->adam_blocks + k.blk_first, k.blk_n, h->params, h->adam_m, h->adam_v, h->grads,
@@ -804,13 +862,40 @@ int wgrad_layer_tensor(FactHandle* h, const bf16_t* A, int lda, int Mo, const bf
   return wgrad(h, A, lda, Mo, B, ldb, No, K, out, ldo, s, slab);
 }
 
+// Shape test of the grouped whole-K wgrad launch for a stack at M tokens (wgrad_layer_group / the supervised-rows batch).
+bool wgrad_group_ok(const FactHandle* h, const Stack& st, int M) {
+  return h->wgrad_big && h->wgrad_tr && !(M & 31) && M >= 512 && !(st.d & 3) && !(st.ff & 3) && st.d >= 160;
+}
+
+// May this fact_forward_backward call run the optimizer inside the wgrad launches (FactHandle::adam_in_wgrad)?  Needs the
+// engine-owned fused step (fact_adam_begin, no gradient callback, no clipping), overwrite semantics for the layer
+// gradients, and EVERY layer of every stack on the grouped launch (16-wide units on both sides of each Dense kernel).
+bool wg_adam_ok(const FactHandle* h, int B) {
+  if (!h->adam_in_wgrad || !h->adam_pending || h->cb || !h->grad_overwrite || !h->fuse_adam_cast || !h->ln_split ||
+      (h->skip & 1) || h->adam.gscale != 1.0f)
+    return false;
+  for (const Stack* st : {&h->cross, &h->motion, &h->audio}) {
+    if (!st->L) continue;
+    if (!wgrad_group_ok(h, *st, B * st->n) || (st->d & 15) || (st->ff & 15)) return false;
+  }
+  return true;
+}
+
+// Hand a problem of a grouped wgrad launch the optimizer state of its Dense kernel (TnGroup::adam).
+void arm_adam(FactHandle* h, TnGroup& g, int i, const DenseW& w) {
+  TnProblem& q = g.p[i];
+  q.p = h->params + w.w.off; q.m1 = h->adam_m + w.w.off; q.v = h->adam_v + w.w.off;
+  q.sd = w.s; q.ldsd = w.lds; q.st = w.t; q.ldst = w.ldt;
+  g.adam = 1; g.lr_t = h->adam.lr_t; g.b1 = h->adam.b1; g.b2 = h->adam.b2; g.eps = h->adam.eps;
+}
+
 // The four weight gradients of one transformer layer as ONE grouped whole-K launch (gemm_big.hip): 160x256
 // tiles, the d-wide operand on the 160-tiled side (d = 800 -> 5 tiles exactly); dW2 = g^T dY is computed as
 // (dY^T g) and stored transposed.  Returns 1 when the shape is not eligible (caller takes the per-GEMM path).
 int wgrad_layer_group(FactHandle* h, const Stack& st, const LayerP& p, const LayerA& a, const bf16_t* xin16,
                       const bf16_t* dpre, const bf16_t* xmid16, const bf16_t* dqkv, int M, hipStream_t s) {
   const int d = st.d, ff = st.ff;
-  if (!h->wgrad_big || !h->wgrad_tr || (M & 31) || M < 512 || (d & 3) || (ff & 3) || d < 160) return 1;
+  if (!wgrad_group_ok(h, st, M)) return 1;
   TnGroup g;
   memset(&g, 0, sizeof(g));
   g.n = 4;
@@ -825,6 +910,9 @@ int wgrad_layer_group(FactHandle* h, const Stack& st, const LayerP& p, const Lay
   set(2, a.a, st.dp, d, xmid16, st.dp, d, G(h, p.wo.w), d, 0);          // dWo[d][d]   = attn^T dx_mid
   set(3, a.h1, st.dp, d, dqkv, st.qp, 3 * d, G(h, p.wqkv.w), 3 * d, 0); // dWqkv[d][3d] = LN1(x)^T dqkv
   g.overwrite = h->grad_overwrite;
+  if (h->wg_adam) {
+    arm_adam(h, g, 0, p.w2); arm_adam(h, g, 1, p.w1); arm_adam(h, g, 2, p.wo); arm_adam(h, g, 3, p.wqkv);
+  }
   CHK(launch_big_tn_group(g, s, h->wgrad_parts));
   return 0;
 }
@@ -1007,8 +1095,10 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
     SrBuf& r = h->sr;
     const int Mr = b.sr_rows, Kc = b.sr_pad;
     {
-      KScope k(h, KP_WGRAD, w, 2.0 * ((double)Mr * ((double)d * ff * 2 + (double)d * d) + (double)M * d * d * 3), 0, 2);
-      bool grouped = h->wgrad_big && h->wgrad_tr && !(M & 31) && M >= 512 && !(d & 3) && !(ff & 3) && d >= 160;
+      KScope k(h, KP_WGRAD, w, 2.0 * ((double)Mr * ((double)d * ff * 2 + (double)d * d) + (double)M * d * d * 3),
+               h->wg_adam ? 28.0 * ((double)d * ff * 2 + (double)d * d * 4) : 0, 2);
+      bool grouped = wgrad_group_ok(h, st, M);
+      if (!grouped && h->wg_adam) return fail(-1, "optimizer-in-wgrad step without the grouped wgrad launch");
       if (grouped) {
         TnGroup g;
         memset(&g, 0, sizeof(g));
@@ -1023,12 +1113,16 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
         set(1, r.h2_c, dp, d, r.dpre_c, fp, ff, G(h, p.w1.w), ff, 0);
         set(2, r.a_c, dp, d, r.xmid16_c, dp, d, G(h, p.wo.w), d, 0);
         g.overwrite = h->grad_overwrite;
+        if (h->wg_adam) {
+          arm_adam(h, g, 0, p.w2); arm_adam(h, g, 1, p.w1); arm_adam(h, g, 2, p.wo);
+        }
         CHK(launch_big_tn_group(g, w, 1));
         memset(&g, 0, sizeof(g));
         g.n = 1;
         g.K = M;
         set(0, a.h1, dp, d, b.dqkv, qp, 3 * d, G(h, p.wqkv.w), 3 * d, 0);
         g.overwrite = h->grad_overwrite;
+        if (h->wg_adam) arm_adam(h, g, 0, p.wqkv);
         CHK(launch_big_tn_group(g, w, 1));
       } else {
         CHK(wgrad_layer_tensor(h, r.g_c, fp, ff, r.dx16_c, dp, d, Kc, G(h, p.w2.w), d, w, b.slab));
@@ -1060,10 +1154,12 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
     return 0;
   }
   {
-    KScope k(h, KP_WGRAD, w, 2.0 * (double)M * ((double)d * ff * 2 + (double)d * d * 4), 0,
-             h->wgrad_big ? h->wgrad_parts : 8);
+    // (with the optimizer in the epilogue the class also moves 28 bytes per layer-kernel parameter: reported beside the FLOPs)
+    KScope k(h, KP_WGRAD, w, 2.0 * (double)M * ((double)d * ff * 2 + (double)d * d * 4),
+             h->wg_adam ? 28.0 * ((double)d * ff * 2 + (double)d * d * 4) : 0, h->wgrad_big ? h->wgrad_parts : 8);
     const int rc = (h->skip & 1) ? 0 : wgrad_layer_group(h, st, p, a, b.xin16, b.dpre, b.xmid16, b.dqkv, M, w);
     if (rc < 0) return rc;
+    if (rc > 0 && h->wg_adam) return fail(-1, "optimizer-in-wgrad step without the grouped wgrad launch");
     if (rc > 0) {
       CHK(wgrad_layer_tensor(h, a.g, fp, ff, b.xin16, dp, d, M, G(h, p.w2.w), d, w, b.slab));
       CHK(wgrad_layer_tensor(h, a.h2, dp, d, b.dpre, fp, ff, M, G(h, p.w1.w), ff, w, b.slab));
@@ -1171,7 +1267,7 @@ int layer_backward(FactHandle* h, Stack& st, int l, int B, float* dx, bf16_t*& d
   }
   KScope* kln = new KScope(h, KP_LN_BWD, s, 0, Md * d * 16.0);
   // (the batch must be flushed AFTER this layer's LayerNorm 1 backward has produced its partials: wgrad_defer)
-  const bool cs = split && h->ln_cs && h->wgrad_defer && d <= 1024;
+  const bool cs = split && h->ln_cs && h->wgrad_defer && d <= 1024 && sc.lnpart_pp[q][0] && sc.lnpart_pp[q][1];
   float* part2 = cs ? sc.lnpart_pp[q][0] : nullptr;
   float* part1 = cs ? sc.lnpart_pp[q][1] : nullptr;
   if (h->skip & 8) {
@@ -1594,6 +1690,9 @@ int fact_destroy(FactHandle* h) {
   if (h->opt) (void)hipStreamDestroy(h->opt);
   if (h->aux) (void)hipStreamDestroy(h->aux);
   if (h->lite) (void)hipStreamDestroy(h->lite);
+  for (BwScratch& sc : h->bw)
+    for (int q = 0; q < kBwBuf; ++q)
+      for (int i = 0; i < 2; ++i) (void)hipFree(sc.lnpart_pp[q][i]);
   (void)hipFree(h->skinny_acc);
   (void)hipFree(h->skinny_acc2);
   (void)hipFree(h->ar_motion);
@@ -1669,6 +1768,10 @@ int fact_set_option(FactHandle* h, const char* key, int value) {
   }
   if (!strcmp(key, "side_stream")) {
     h->use_side = value;
+    return 0;
+  }
+  if (!strcmp(key, "adam_in_wgrad")) {  // optimizer step of the layer kernels inside their wgrad launches (FactHandle)
+    h->adam_in_wgrad = value != 0;
     return 0;
   }
   return fail(-1, std::string("unknown option ") + key + " (A/B and ablation knobs: fact_debug_set_option, fact_hip_debug.h)");
@@ -1748,6 +1851,7 @@ int fact_debug_set_option(FactHandle* h, const char* key, int value) {
     return 0;
   }
   if (!strcmp(key, "ln_cs")) {  // 0 = col_tasks pass; 1 = partials from the dx kernel, 4 rows per wave; 2 = 2 rows per wave
+    if (value) CHK(alloc_ln_cs(h));
     h->ln_cs = value;
     if (value) ln_set_cs_rows(value == 2 ? 2 : 4);  // process-wide kernel shape
     return 0;
@@ -1801,6 +1905,7 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
   // supervised-rows shortcut (SrBuf): the last cross-modal layer and the head on the B*T rows the loss reads
   const bool sr = h->sr_rows && h->ln_split && cr.L >= 1 && T <= 32 && 4 * T <= cr.n &&
                   rups((size_t)B * T, 64) <= (size_t)h->sr.rows_max;
+  h->wg_adam = wg_adam_ok(h, B);
   CHK(model_forward_hidden(h, motion, (size_t)mo.n * mo.feat, audio, (size_t)au.n * au.feat, B, s, sr ? T : 0));
   HIPCHK(hipMemsetAsync(h->scalars, 0, 16 * sizeof(float), s));
   if (sr) {
@@ -1887,6 +1992,7 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
     stream_after(h, h->opt, s);
     h->adam_pending = false;
   }
+  h->wg_adam = false;
   // the caller's stream has joined the side stream: no reader of the backward scratch is left
   for (BwScratch& sc : h->bw) {
     for (int q = 0; q < kBwBuf; ++q) sc.ev_batch[q] = nullptr;
@@ -1978,8 +2084,6 @@ int fact_kprof(FactHandle* h, int on) {
   h->kp.on = on != 0;
   h->kp.recs.clear();
   h->kp.used = 0;
-  g_fact_note_on = h->kp.on;
-  g_fact_notes.clear();
   return 0;
 }
 
@@ -2220,6 +2324,27 @@ int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const voi
   CHK(launch_big_tn_group(g, (hipStream_t)stream, g_op_tn_parts));
   return 0;
 }
+int fact_op_gemm_tn_group_adam(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                               float* const* p, float* const* m, float* const* v, void* const* sd, const int* lds,
+                               void* const* st, const int* ldt, const int* Mo, const int* No, const int* trans, int K,
+                               float lr_t, float beta1, float beta2, float eps, void* stream) {
+  if (n < 1 || n > TN_GROUP_MAX) return fail(-1, "1..4 problems");
+  TnGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  g.K = K;
+  g.overwrite = 1;
+  g.adam = 1; g.lr_t = lr_t; g.b1 = beta1; g.b2 = beta2; g.eps = eps;
+  for (int i = 0; i < n; ++i) {
+    TnProblem& q = g.p[i];
+    q.A = (const bf16_t*)A[i]; q.lda = lda[i]; q.B = (const bf16_t*)B[i]; q.ldb = ldb[i];
+    q.M = Mo[i]; q.N = No[i]; q.trans_out = trans[i];
+    q.out = p[i]; q.ldo = trans[i] ? Mo[i] : No[i];  // (out itself is not written; its pitch indexes p / m / v)
+    q.p = p[i]; q.m1 = m[i]; q.v = v[i]; q.sd = (bf16_t*)sd[i]; q.ldsd = lds[i]; q.st = (bf16_t*)st[i]; q.ldst = ldt[i];
+  }
+  CHK(launch_big_tn_group(g, (hipStream_t)stream, g_op_tn_parts));
+  return 0;
+}
 int fact_debug_gemm_tn_cfg(int v) {  // low byte: main loop (0 staggered, 1 / 2 fragment prefetch); bits 8..: launches per group of the op
   gemm_set_tn_cfg(v & 0xff);
   g_op_tn_parts = (v >> 8) > 0 ? (v >> 8) : 1;
@@ -2379,7 +2504,7 @@ int fact_debug_attn_force_tiled(int on) {
 // Occupies `nwg` CUs for ~`micros` microseconds: one 256-thread workgroup per CU (96 KiB of LDS each keeps a second one
 // off the CU), spinning on the shader clock.  Stand-in for a communication kernel that holds CUs while the step runs
 // (tools/attic/cu_hog_probe.py: what does the train step lose when N CUs are not available to it?).
-__global__ __launch_bounds__(256) void cu_hog_kernel(long long cycles, unsigned* sink, int mode) {
+static __global__ __launch_bounds__(256) void cu_hog_kernel(long long cycles, unsigned* sink, int mode) {
   extern __shared__ unsigned char hog_lds[];
   unsigned acc = 0;
   if (mode & 2) {  // no clock polling: a counted sleep loop (~64 * 64 cycles per trip at the shader clock)

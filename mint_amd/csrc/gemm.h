@@ -96,6 +96,17 @@ struct TnProblem {
   int M, N;        // A columns (the 160-tiled side), B columns (the 256-tiled side)
   int trans_out;
   int tiles_m, tile_begin;  // filled by the launcher
+  // Fused optimizer step (TnGroup::adam; round 5).  The whole-K launch owns every element of `out` exactly once, so the
+  // product IS the final gradient of that weight: instead of storing it, the epilogue applies the Keras-Adam update to the
+  // fp32 master weight and both moments (same element index as `out`) and writes the two bf16 weight shadows of the
+  // tensor - 28 bytes per parameter where "store gradient + optimizer pass" moves 4 + 32, and no optimizer pass left to
+  // expose at the end of the step.  `out` is not written.
+  float* p;      // fp32 master weights     [rows of out][ldo]
+  float* m1;     // Adam first moment
+  float* v;      // Adam second moment
+  bf16_t* sd;    // bf16 shadow in out's orientation   [rows of out][ldsd]
+  bf16_t* st;    // bf16 shadow, transposed            [cols of out][ldst]
+  int ldsd, ldst;
 };
 struct TnGroup {
   TnProblem p[TN_GROUP_MAX];
@@ -103,6 +114,8 @@ struct TnGroup {
   int K;
   int tile0;  // first logical tile of this launch (filled by the launcher)
   int overwrite;  // 1: out = product (plain stores; every output element belongs to exactly one tile), 0: out += product
+  int adam;       // 1: fused optimizer epilogue (TnProblem::p ...); every M, N a multiple of 16, overwrite semantics
+  float lr_t, b1, b2, eps;  // Keras Adam: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t), epsilon outside the bias correction
 };
 // `parts` > 1 cuts the group's tiles into that many launches (same stream, in order) of about equal size: each
 // then occupies only ~tiles/parts CUs, which leaves room for the CU-exclusive kernels of another stream.

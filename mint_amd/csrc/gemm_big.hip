@@ -1024,7 +1024,108 @@ DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f
 // Logical block id -> (problem, m-tile, n-tile), m fastest: with 5 m-tiles per 800-row side the ~24 tiles
 // an XCD owns form a near-square patch (5 x 5 operand panels per K step instead of 24 + 24).
 // -------------------------------------------------------------------------------------------------
-template <class C, int PF>
+// Fused optimizer epilogue of the grouped TN kernel (TnGroup::adam, gemm.h).  On entry acc holds the FINAL gradient of
+// the wave's sub-tile (whole-K launch, overwrite semantics) in the lane layout of the branch that produced it:
+//   !TRANS (swapped roles): lane = row m = mrow[i] + (lane & 15), 4 consecutive n = ncol[j] + (lane >> 4) * 4, out[m][n]
+//    TRANS                : lane = column n = ncol[j] + (lane & 15), 4 consecutive m = mrow[i] + (lane >> 4) * 4, out[n][m]
+// Per accumulator row i the wave requests p / m / v of all NR tiles (one row ahead of the arithmetic), updates them with
+// adam1 (common.h: the optimizer pass's own arithmetic), stores them back and writes the bf16 shadow that has out's
+// orientation straight from the registers (8 bytes per lane).  The TRANSPOSED shadow goes through a wave-private LDS tile
+// (the ring is idle after the main loop's closing vmcnt(0) + barrier): bf16 elements are scattered in transposed order,
+// then read back as 16-byte row chunks and stored as whole row segments.  No barrier: the tile belongs to one wave.
+template <class C, bool TRANS>
+DEVINL void tn_adam_epilogue(unsigned char* smem, const TnProblem& pr, float lr_t, float b1, float b2, float eps,
+                             f32x4 (&acc)[C::MR][C::NR], const int (&mrow)[C::MR], const int (&ncol)[C::NR], int m0,
+                             int n0, int wave, int wm, int wn, int lane) {
+  constexpr int MR = C::MR, NR = C::NR;
+  constexpr int TROWS = TRANS ? MR * 16 : NR * 16;  // rows of the transposed shadow this wave owns
+  constexpr int TCOLS = TRANS ? NR * 16 : MR * 16;  // contiguous elements per row
+  constexpr int PITCH = TCOLS + 8;                  // bf16 elements: 16-byte aligned rows, an odd number of 16-byte slots
+  static_assert(C::NW * TROWS * PITCH * 2 <= C::LDS_BYTES, "transposition tiles fit the idle ring");
+  bf16_t* tb = reinterpret_cast<bf16_t*>(smem) + wave * (TROWS * PITCH);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  f32x4 pv[2][NR], mv[2][NR], vv[2][NR];
+  auto elem = [&](int i, int j, bool& ok) -> size_t {  // element offset of this lane's 4 values of tile (i, j)
+    if constexpr (!TRANS) {
+      const int m = mrow[i] + l15, n = ncol[j] + l4 * 4;
+      ok = m < pr.M && n + 3 < pr.N;
+      return (size_t)m * pr.ldo + n;
+    } else {
+      const int m = mrow[i] + l4 * 4, n = ncol[j] + l15;
+      ok = n < pr.N && m + 3 < pr.M;
+      return (size_t)n * pr.ldo + m;
+    }
+  };
+  auto request = [&](int i, int b) {
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      bool ok;
+      const size_t o = elem(i, j, ok);
+      if (ok) {
+        pv[b][j] = *reinterpret_cast<const f32x4*>(pr.p + o);
+        mv[b][j] = *reinterpret_cast<const f32x4*>(pr.m1 + o);
+        vv[b][j] = *reinterpret_cast<const f32x4*>(pr.v + o);
+      }
+    }
+  };
+  request(0, 0);
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+    const int b = i & 1;
+    if (i + 1 < MR) request(i + 1, b ^ 1);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      bool ok;
+      const size_t o = elem(i, j, ok);
+      if (!ok) continue;
+      f32x4 pn = pv[b][j], mn = mv[b][j], vn = vv[b][j];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pj = pn[r], mj = mn[r], vj = vn[r];
+        adam1(pj, mj, vj, acc[i][j][r], lr_t, b1, b2, eps);
+        pn[r] = pj; mn[r] = mj; vn[r] = vj;
+      }
+      *reinterpret_cast<f32x4*>(pr.p + o) = pn;
+      *reinterpret_cast<f32x4*>(pr.m1 + o) = mn;
+      *reinterpret_cast<f32x4*>(pr.v + o) = vn;
+      const bf16x4 w16 = {(bf16_t)pn[0], (bf16_t)pn[1], (bf16_t)pn[2], (bf16_t)pn[3]};
+      if constexpr (!TRANS) {
+        const int m = mrow[i] + l15, n = ncol[j] + l4 * 4;
+        *reinterpret_cast<bf16x4*>(pr.sd + (size_t)m * pr.ldsd + n) = w16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[(j * 16 + l4 * 4 + r) * PITCH + i * 16 + l15] = w16[r];
+      } else {
+        const int m = mrow[i] + l4 * 4, n = ncol[j] + l15;
+        *reinterpret_cast<bf16x4*>(pr.sd + (size_t)n * pr.ldsd + m) = w16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[(i * 16 + l4 * 4 + r) * PITCH + j * 16 + l15] = w16[r];
+      }
+    }
+  }
+  // transposed shadow: 16-byte chunks of the wave's TROWS x TCOLS tile -> st[row][col .. col + 7]
+  constexpr int CPR = TCOLS / 8, ITEMS = TROWS * CPR;
+  static_assert(ITEMS % 64 == 0, "whole wave trips");
+#pragma unroll
+  for (int it = 0; it < ITEMS / 64; ++it) {
+    const int idx = it * 64 + lane;
+    const int row = idx / CPR, c = idx - row * CPR;
+    // local 16-wide unit of the row / of the chunk -> global index (the units of a wave are not contiguous: TnImg::unit_of)
+    int gm, gn;
+    if constexpr (!TRANS) {
+      gn = n0 + TnImg<C::BN>::template unit_of<C::WGN, NR>(wn, row >> 4) * 16 + (row & 15);
+      gm = m0 + TnImg<C::BM>::template unit_of<C::WGM, MR>(wm, c >> 1) * 16 + (c & 1) * 8;
+      if (gn < pr.N && gm + 7 < pr.M)
+        *reinterpret_cast<u32x4*>(pr.st + (size_t)gn * pr.ldst + gm) = *reinterpret_cast<const u32x4*>(tb + row * PITCH + c * 8);
+    } else {
+      gm = m0 + TnImg<C::BM>::template unit_of<C::WGM, MR>(wm, row >> 4) * 16 + (row & 15);
+      gn = n0 + TnImg<C::BN>::template unit_of<C::WGN, NR>(wn, c >> 1) * 16 + (c & 1) * 8;
+      if (gm < pr.M && gn + 7 < pr.N)
+        *reinterpret_cast<u32x4*>(pr.st + (size_t)gm * pr.ldst + gn) = *reinterpret_cast<const u32x4*>(tb + row * PITCH + c * 8);
+    }
+  }
+}
+
+template <class C, int PF, bool ADAM = false>
 __global__ __launch_bounds__(C::NW * 64, 1) void big_tn_kernel(const TnGroup g) {
   constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -1079,6 +1180,10 @@ __global__ __launch_bounds__(C::NW * 64, 1) void big_tn_kernel(const TnGroup g) 
   if (!pr.trans_out) {
     if constexpr (PF) tn_mainloop_pf<C, true, PF >= 2, (PF > 2 ? PF - 2 : 0)>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
     else big_mainloop<C, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+    if constexpr (ADAM) {
+      tn_adam_epilogue<C, false>(smem, pr, g.lr_t, g.b1, g.b2, g.eps, acc, mrow, ncol, m0, n0, wave, wm, wn, lane);
+      return;
+    }
     // lane: row m = .. + (lane&15), 4 consecutive n.  All old values are requested before the first store.
     float4 old[MR][NR];
 #pragma unroll
@@ -1107,6 +1212,10 @@ __global__ __launch_bounds__(C::NW * 64, 1) void big_tn_kernel(const TnGroup g) 
   } else {
     if constexpr (PF) tn_mainloop_pf<C, false, PF >= 2, (PF > 2 ? PF - 2 : 0)>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
     else big_mainloop<C, true, false>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+    if constexpr (ADAM) {
+      tn_adam_epilogue<C, true>(smem, pr, g.lr_t, g.b1, g.b2, g.eps, acc, mrow, ncol, m0, n0, wave, wm, wn, lane);
+      return;
+    }
     // un-swapped roles: lane holds 4 consecutive m of column n = .. + (lane&15); out is [n][m]
     float4 old[MR][NR];
 #pragma unroll
@@ -1352,9 +1461,18 @@ int launch_big_tn_group_t(TnGroup g, hipStream_t s, int parts) {
     q.tile_begin = total;
     total += q.tiles_m * ((q.N + C::BN - 1) / C::BN);
   }
+  if (g.adam) {  // fused optimizer epilogue: whole 16-wide units only, a complete set of arenas and shadows per problem
+    if (!g.overwrite) return -3;
+    for (int i = 0; i < g.n; ++i) {
+      const TnProblem& q = g.p[i];
+      if ((q.M & 15) || (q.N & 15) || !q.p || !q.m1 || !q.v || !q.sd || !q.st || (q.ldsd & 7) || (q.ldst & 7)) return -3;
+      if (((uintptr_t)q.p & 15) || ((uintptr_t)q.m1 & 15) || ((uintptr_t)q.v & 15) || ((uintptr_t)q.sd & 15) || ((uintptr_t)q.st & 15)) return -5;
+    }
+  }
   static bool once = false;
   if (!once) {
-    if (int rc = allow_lds(big_tn_kernel<C, PF>, C::LDS_BYTES)) return rc;
+    if (int rc = allow_lds(big_tn_kernel<C, PF, false>, C::LDS_BYTES)) return rc;
+    if (int rc = allow_lds(big_tn_kernel<C, PF, true>, C::LDS_BYTES)) return rc;
     once = true;
   }
   if (parts < 1) parts = 1;
@@ -1362,7 +1480,8 @@ int launch_big_tn_group_t(TnGroup g, hipStream_t s, int parts) {
     const int lo = (int)((long long)total * i / parts), hi = (int)((long long)total * (i + 1) / parts);
     if (hi <= lo) continue;
     g.tile0 = lo;
-    FACT_LAUNCH((big_tn_kernel<C, PF>), dim3(hi - lo), dim3(C::NW * 64), C::LDS_BYTES, s, g);
+    if (g.adam) FACT_LAUNCH((big_tn_kernel<C, PF, true>), dim3(hi - lo), dim3(C::NW * 64), C::LDS_BYTES, s, g);
+    else FACT_LAUNCH((big_tn_kernel<C, PF, false>), dim3(hi - lo), dim3(C::NW * 64), C::LDS_BYTES, s, g);
   }
   return 0;
 }

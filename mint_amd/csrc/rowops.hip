@@ -615,11 +615,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, float
   }
 }
 
-DEVINL void adam1(float& p, float& m, float& v, float g, float lr_t, float b1, float b2, float eps) {
-  m = b1 * m + (1.f - b1) * g;
-  v = b2 * v + (1.f - b2) * g * g;
-  p -= lr_t * m / (sqrtf(v) + eps);
-}
+// adam1: common.h (shared with the fused optimizer epilogue of the grouped wgrad kernel, gemm_big.hip)
 
 // G16 != nullptr (data parallel with bf16 gradient buckets): the gradient is read from the all-reduced bf16 buffer
 // (indexed like the fp32 arena) instead of from G - no cast back into the arena; G is still zeroed for the next step.

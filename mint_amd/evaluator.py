@@ -31,9 +31,23 @@ class SingleTaskEvaluator:
             metric.reset_states()
 
     def eval_step(self, iterator):
-        inputs = sharding.shard_inputs(next(iterator), self.rank, self.world_size)  # this replica's sequences
-        if int(inputs["motion_input"].shape[0]) == 0:
-            return None, []  # more ranks than sequences in this batch
+        """Returns (outputs of THIS rank's sequences, paths this rank saved).  Metrics, when there are any, are updated
+        on every rank with the GLOBAL batch and the gathered global outputs, so eval_end() reports the same whole-set
+        value everywhere (the reference's strategy-aware Keras metrics aggregate over replicas); FACT's own metric list
+        is empty and the gather is skipped."""
+        global_inputs = next(iterator)
+        inputs = sharding.shard_inputs(global_inputs, self.rank, self.world_size)  # this replica's sequences
+        total = int(global_inputs["motion_input"].shape[0])
+        if int(inputs["motion_input"].shape[0]) == 0:  # more ranks than sequences in this batch
+            if self.metrics and self.world_size > 1:  # still a party to the gather the other ranks run
+                import torch.distributed as dist
+                seed = torch.as_tensor(global_inputs["motion_input"])
+                dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else seed.device
+                empty = torch.zeros((0, int(seed.shape[1]) + self.steps, int(seed.shape[2])), dtype=seed.dtype, device=dev)
+                full = sharding.gather_rows(empty, total, self.rank, self.world_size)
+                for metric in self.metrics:
+                    metric.update_state(global_inputs, full)
+            return None, []
         # [batch, steps, dim] -> [batch, seed + steps, dim]   (single_task_evaluator.py:69-71)
         outputs = self.model.infer_auto_regressive(inputs, steps=self.steps)
         seed = torch.as_tensor(inputs["motion_input"]).to(outputs.device, outputs.dtype)
@@ -46,8 +60,14 @@ class SingleTaskEvaluator:
                 path = os.path.join(self.output_dir, "%s_%s.npy" % (inputs["motion_name"][i], inputs["audio_name"][i]))
                 np.save(path, host[i])
                 paths.append(path)
-        for metric in self.metrics:
-            metric.update_state(inputs, outputs)
+        if self.metrics:
+            if self.world_size > 1:
+                full = sharding.gather_rows(outputs, total, self.rank, self.world_size)
+                for metric in self.metrics:
+                    metric.update_state(global_inputs, full)
+            else:
+                for metric in self.metrics:
+                    metric.update_state(inputs, outputs)
         return outputs, paths
 
     def eval_end(self):

@@ -355,6 +355,7 @@ class FACTModel:
         """In-step kernel-class timing (fact_kprof): `kernel_profile(True)` arms it, `kernel_profile()` reads the
         records as a list of dicts {name, launches, total_ms, flops, bytes} (device synchronised)."""
         self._require_built()
+        L.need_debug_abi("kernel_profile()")
         lib = L.lib()
         if on is not None:
             L.check(lib.fact_kprof(self._h, 1 if on else 0))
@@ -379,12 +380,14 @@ class FACTModel:
         return out
 
     def _apply_option(self, key, value, debug):
+        if debug:
+            L.need_debug_abi("debug_option(%r)" % key)
         fn = L.lib().fact_debug_set_option if debug else L.lib().fact_set_option
         L.check(fn(self._h, key.encode(), int(value)))
 
     def set_option(self, key, value):
-        """Engine option of the production surface (include/fact_hip.h: sr_rows, grad_overwrite, side_stream,
-        aux_stream).  Remembered and re-applied when build() re-creates the handle for a larger batch - options are
+        """Engine option of the production surface (include/fact_hip.h: sr_rows, grad_overwrite, adam_in_wgrad,
+        side_stream, aux_stream).  Remembered and re-applied when build() re-creates the handle for a larger batch - options are
         per handle, and e.g. a trainer that set grad_overwrite must not silently fall back to accumulation."""
         if key not in L.PUBLIC_OPTIONS:
             raise ValueError("%r is not a production option %s; test / bench knobs: debug_option()" % (

@@ -70,3 +70,33 @@ def test_kernel_name_and_cu_share_come_from_the_engine_record(bench):
         {"count": 31, "grid": 1440, "block": 256, "lds_bytes": 0, "workgroups_per_cu": 8, "name": "ln_fwd_kernel<4>"}]})
     assert full["cus_held"] == 256
     assert bench.class_kernels({"name": "x", "kernels": []}) == {"kernel": "x", "cu_share": None}
+
+
+# ---- `python bench.py --gpus N` is its own launcher (round 5): N ranks on one node, one process per GPU --------------------
+def test_launcher_argv_is_the_drivers_command(bench):
+    cmd = bench.launcher_argv(8, "/x/bench.py", ["--gpus", "8", "--steps", "5"], 29511, python="python")
+    assert cmd == ["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                   "127.0.0.1", "--master-port", "29511", "/x/bench.py", "--gpus", "8", "--steps", "5"]
+
+
+def test_gpus_flag_spawns_ranks_only_without_a_launcher(bench):
+    seen = {}
+
+    def fake_exec(path, argv, env):
+        seen.update(path=path, argv=argv, env=env)
+
+    # N = 1 and "already under a launcher" never re-exec
+    assert bench.maybe_spawn_ranks(["bench.py"], {}, fake_exec) is None
+    assert bench.maybe_spawn_ranks(["bench.py", "--gpus", "1"], {}, fake_exec) is None
+    assert bench.maybe_spawn_ranks(["bench.py", "--gpus", "4"], {"WORLD_SIZE": "4"}, fake_exec) is None
+    assert not seen
+    cmd = bench.maybe_spawn_ranks(["bench.py", "--gpus=2", "--dist-backend", "gloo", "--steps", "3"], {"PATH": "/bin"},
+                                  fake_exec)
+    assert seen["argv"] == cmd and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-5:] == ["--gpus=2", "--dist-backend", "gloo", "--steps", "3"] and cmd[-6].endswith("bench.py")
+    # the ranks inherit what must be set before the HIP runtime starts
+    assert seen["env"]["GPU_MAX_HW_QUEUES"] == "7" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert seen["env"]["PATH"] == "/bin"
+    assert bench.requested_gpus(["--steps", "5", "--gpus", "8"]) == 8 and bench.requested_gpus(["--steps", "5"]) == 1

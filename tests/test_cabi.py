@@ -31,11 +31,35 @@ def test_header_symbols_are_exported_and_bound(lib):
     public, debug = _declared(), _declared(DEBUG_HEADER)
     assert len(public) >= 20 and len(debug) >= 20 and not set(public) & set(debug)
     for n in public + debug:
-        assert hasattr(lib, n), "libfact_hip.so does not export %s" % n
+        assert hasattr(lib, n), "libfact_hip_dbg.so does not export %s" % n
         assert n in L.SIGNATURES, "mint_amd/_lib.py has no ctypes signature for %s" % n
     for n in L.SIGNATURES:
         assert n in public or n in debug, "%s bound in _lib.py but declared in neither header" % n
     assert set(debug) == set(L.DEBUG_SYMBOLS)
+
+
+def _exported(path):
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    # functions (T / W) and data objects; hipcc's per-translation-unit id objects (__hip_cuid_*) are not an interface
+    return sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in ("T", "W", "D", "B")
+                  and not l.split()[-1].startswith("__hip_cuid_"))
+
+
+def test_production_library_exports_exactly_the_public_header(lib):
+    """libfact_hip.so (what a host binds) is built with -fvisibility=hidden: its dynamic symbol table holds the entry points
+    of include/fact_hip.h and NOTHING else - no fact_debug_* / fact_op_* / fact_probe_* / fact_kprof* (the timing-only
+    `skip` mask is not one dlsym away), no internal C++ launcher.  libfact_hip_dbg.so (tests, bench.py) adds the debug
+    header and still no internals."""
+    public, debug = _declared(), _declared(DEBUG_HEADER)
+    assert os.path.exists(L.PROD_LIB_PATH) and os.path.exists(L.DEBUG_LIB_PATH)
+    assert _exported(L.PROD_LIB_PATH) == public
+    assert _exported(L.DEBUG_LIB_PATH) == sorted(public + debug)
+    prod = C.CDLL(L.PROD_LIB_PATH)
+    assert prod.fact_abi_version() == 2
+    for n in debug:
+        assert not hasattr(prod, n), n
+    assert L.DEBUG_ABI and L.LIB_PATH == L.DEBUG_LIB_PATH  # tests/conftest.py selected the test / bench build
 
 
 def test_public_header_carries_no_lab_bench():
@@ -51,7 +75,7 @@ def test_public_header_carries_no_lab_bench():
 
 
 def test_abi_version_and_struct_layout(lib):
-    assert lib.fact_abi_version() == 1
+    assert lib.fact_abi_version() == 2
     assert C.sizeof(L.FactStackCfg) == 24 and C.sizeof(L.FactConfig) == 3 * 24 + 8
     assert C.sizeof(L.FactParamDesc) == 96 + 8 + 12 + 4  # name, offset, rows/cols/kind, padding
     assert C.sizeof(L.FactArenas) == 32

@@ -359,6 +359,69 @@ def test_gemm_tn_group_small_dims(tn_group_loop):
             _close(out, 1.0 + (ref.t() if tr else ref), 1e-3, 2e-3 * math.sqrt(K), "tn group %s tr%d" % ((K, Mo, No), tr))
 
 
+def _adam_ref(p, m, v, g, lr_t, b1, b2, eps):
+    """Keras Adam on fp32 tensors (the arithmetic of common.h adam1, in torch fp32)."""
+    m = b1 * m + (1.0 - b1) * g
+    v = b2 * v + (1.0 - b2) * g * g
+    return p - lr_t * m / (torch.sqrt(v) + eps), m, v
+
+
+@pytest.mark.parametrize("dims", [(5760, 800, 3072), (320, 800, 3072), (96, 160, 512), (1440, 1536, 384)],
+                         ids=["fact_v5", "supervised_rows", "small", "d1536"])
+def test_gemm_tn_group_adam_epilogue(tn_group_loop, dims):
+    """The grouped whole-K wgrad launch with the optimizer in its epilogue (round 5, engine option adam_in_wgrad) against
+    torch fp32: the gradient A^T B never reaches memory - master weights and both moments are updated in place, the bf16
+    shadow in the weight's own orientation and the TRANSPOSED shadow (through the wave-private LDS tile) equal the bf16
+    rounding of the updated weights exactly, elements of the padded shadow pitch stay untouched.  All four problems of
+    a layer (dW2 computed transposed; ragged 2400- and 800-wide column sides = partial 256-tiles)."""
+    K, d, ff = dims
+    g = torch.Generator(device=DEV).manual_seed(77)
+    rp = lambda c: (c + 63) // 64 * 64
+
+    def mk(cols):
+        t = torch.zeros(K, rp(cols), device=DEV, dtype=torch.bfloat16)
+        t[:, :cols] = _bf(torch.randn(K, cols, device=DEV, generator=g))
+        return t
+    xin, gact, h2, dpre, att, xmid, h1, dqkv = mk(d), mk(ff), mk(d), mk(ff), mk(d), mk(d), mk(d), mk(3 * d)
+    # (A, Mo, B, No, trans): the weight is [Mo][No], or [No][Mo] when trans
+    probs = [(xin, d, gact, ff, 1), (h2, d, dpre, ff, 0), (att, d, xmid, d, 0), (h1, d, dqkv, 3 * d, 0)]
+    lr_t, b1, b2, eps = 3e-3, 0.9, 0.999, 1e-7
+    state, refs = [], []
+    for (A, Mo, B, No, tr) in probs:
+        R, Cc = (No, Mo) if tr else (Mo, No)
+        p = torch.randn(R, Cc, device=DEV, generator=g) * 0.05
+        m = torch.randn(R, Cc, device=DEV, generator=g) * 1e-3
+        v = torch.rand(R, Cc, device=DEV, generator=g) * 1e-5
+        s16 = torch.full((R, rp(Cc)), 7.0, device=DEV, dtype=torch.bfloat16)
+        t16 = torch.full((Cc, rp(R)), 7.0, device=DEV, dtype=torch.bfloat16)
+        grad = A[:, :Mo].float().t() @ B[:, :No].float()
+        refs.append(_adam_ref(p.clone(), m.clone(), v.clone(), grad.t() if tr else grad, lr_t, b1, b2, eps))
+        state.append((p, m, v, s16, t16))
+    n = len(probs)
+    VP, IA = C.c_void_p * n, C.c_int * n
+    arr = lambda f: VP(*[f(i) for i in range(n)])
+    L.check(L.lib().fact_op_gemm_tn_group_adam(
+        n, arr(lambda i: probs[i][0].data_ptr()), IA(*[q[0].stride(0) for q in probs]),
+        arr(lambda i: probs[i][2].data_ptr()), IA(*[q[2].stride(0) for q in probs]),
+        arr(lambda i: state[i][0].data_ptr()), arr(lambda i: state[i][1].data_ptr()), arr(lambda i: state[i][2].data_ptr()),
+        arr(lambda i: state[i][3].data_ptr()), IA(*[st[3].stride(0) for st in state]),
+        arr(lambda i: state[i][4].data_ptr()), IA(*[st[4].stride(0) for st in state]),
+        IA(*[q[1] for q in probs]), IA(*[q[3] for q in probs]), IA(*[q[4] for q in probs]), K,
+        lr_t, b1, b2, eps, L.cur_stream()))
+    _sync()
+    for i, ((p, m, v, s16, t16), (pr, mr, vr)) in enumerate(zip(state, refs)):
+        R, Cc = p.shape
+        what = "problem %d" % i
+        # the gradient differs from the torch matmul by fp32 summation order (~1e-6 * sqrt(K) relative): m, v follow it
+        _close(m, mr, 1e-3, 1e-6 * math.sqrt(K), what + " m")
+        _close(v, vr, 2e-3, 1e-8 * K, what + " v")
+        # an Adam step moves a weight by at most ~lr_t: two correct updates differ by a small fraction of that
+        assert float((p - pr).abs().max()) < 0.05 * lr_t, (what, float((p - pr).abs().max()))
+        assert torch.equal(s16[:, :Cc], p.to(torch.bfloat16)), what + " shadow"
+        assert torch.equal(t16[:, :R], p.t().to(torch.bfloat16)), what + " transposed shadow"
+        assert bool((s16[:, Cc:] == 7.0).all()) and bool((t16[:, R:] == 7.0).all()), what + " shadow padding written"
+
+
 # ------------------------------------------------------------------------------------------------
 # LayerNorm
 # ------------------------------------------------------------------------------------------------

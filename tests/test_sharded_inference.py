@@ -62,14 +62,34 @@ def test_shard_inputs_cuts_per_sample_entries_only():
     assert sharding.gather_rows(b["motion_input"], SEQS, 0, 1) is b["motion_input"]
 
 
+class _MeanAbs:
+    """A metric in the evaluator's protocol (reset_states / update_state(inputs, outputs) / result)."""
+    name = "mean_abs"
+
+    def reset_states(self):
+        self.s, self.n, self.names = 0.0, 0, []
+
+    def update_state(self, inputs, outputs):
+        self.s += float(outputs.abs().sum())
+        self.n += outputs.numel()
+        self.names += list(inputs["motion_name"])
+
+    def result(self):
+        return (self.s / max(self.n, 1), tuple(self.names))
+
+
 def _worker(rank, world, path, outdir, q):
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
     torch.set_num_threads(1)
-    ev = SingleTaskEvaluator([_global_batch()], _OracleSampler(), [], output_dir=outdir, steps=STEPS)
+    ev = SingleTaskEvaluator([_global_batch()], _OracleSampler(), [_MeanAbs()], output_dir=outdir, steps=STEPS)
     assert (ev.rank, ev.world_size) == (rank, world)
+    ev.eval_begin()
     outputs, paths = ev.eval_step(iter(ev.eval_dataset))
     full = sharding.gather_rows(outputs, SEQS)
+    # metrics saw the GLOBAL batch and the gathered outputs: the same whole-set value on every rank
+    m, names = ev.eval_end()["mean_abs"]
+    assert names == tuple("m%d" % i for i in range(SEQS)) and abs(m - float(full.abs().mean())) < 1e-12, (rank, m, names)
     q.put((rank, full.numpy().copy(), [os.path.basename(p) for p in paths]))
     dist.barrier()
     dist.destroy_process_group()

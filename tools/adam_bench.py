@@ -1,4 +1,5 @@
 """Stand-alone timing + equality check of the fused Adam + shadow kernels (engine option adam_variant; FACT_ADAM_TW)."""
+import os as _os; _os.environ.setdefault("FACT_DEBUG_ABI", "1")  # these tools drive the test / bench surface (mint_amd/_lib.py)
 import os
 import sys
 

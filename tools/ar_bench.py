@@ -1,4 +1,5 @@
 """Auto-regressive generation throughput (BASELINE.json configs[3] shape per GPU: 32 sequences)."""
+import os as _os; _os.environ.setdefault("FACT_DEBUG_ABI", "1")  # these tools drive the test / bench surface (mint_amd/_lib.py)
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,7 @@
 """Attention micro-benchmark: runs the attention op (forward + backward) at FACT's shapes for each kernel family
 and prints the relative error vs torch fp32; per-kernel times come from rocprofv3 around this script
 (tools/attn_prof.sh) - HIP-event wall time of the whole op (incl. the head-scatter GEMM of the op) is printed too."""
+import os as _os; _os.environ.setdefault("FACT_DEBUG_ABI", "1")  # these tools drive the test / bench surface (mint_amd/_lib.py)
 import os
 import sys
 

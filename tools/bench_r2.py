@@ -4,6 +4,7 @@
   * a layer's four weight gradients: round-1 path (128x128 TN kernel, split-K slabs + reduce, 4 + 4 launches)
     vs the grouped whole-K launch (160x256 tiles).
 Prints one line per (shape, variant): microseconds, TFLOP/s, relative error vs torch fp32."""
+import os as _os; _os.environ.setdefault("FACT_DEBUG_ABI", "1")  # these tools drive the test / bench surface (mint_amd/_lib.py)
 import ctypes as C
 import os
 import sys

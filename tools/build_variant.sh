@@ -9,10 +9,11 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; unit=$2; shift 2
 mkdir -p $R/tools/bin /tmp/fact_variant
 [ -f $R/mint_amd/lib/obj/gemm.o ] || $R/mint_amd/csrc/build.sh
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result "$@" -c $R/mint_amd/csrc/$unit.hip -o /tmp/fact_variant/$unit.$name.o
+# (the variant is a test / bench build: engine.hip / probe.hip with the debug surface, mint_amd/csrc/build.sh)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fvisibility-inlines-hidden -Wno-unused-result -DFACT_DEBUG_ABI "$@" -c $R/mint_amd/csrc/$unit.hip -o /tmp/fact_variant/$unit.$name.o
 objs=""
-for f in gemm gemm_big rowops attention engine probe; do
-  if [ $f = $unit ]; then objs="$objs /tmp/fact_variant/$unit.$name.o"; else objs="$objs $R/mint_amd/lib/obj/$f.o"; fi
+for f in gemm gemm_big rowops attention engine_dbg probe_dbg; do
+  if [ ${f%_dbg} = $unit ]; then objs="$objs /tmp/fact_variant/$unit.$name.o"; else objs="$objs $R/mint_amd/lib/obj/$f.o"; fi
 done
-hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/bin/libfact_$name.so $objs
+hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--version-script=$R/mint_amd/csrc/exports.map -o $R/tools/bin/libfact_$name.so $objs
 echo "built tools/bin/libfact_$name.so"

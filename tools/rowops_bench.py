@@ -1,4 +1,5 @@
 """Stand-alone timing of the HBM-bound row kernels at FACT sizes (HIP-event timing)."""
+import os as _os; _os.environ.setdefault("FACT_DEBUG_ABI", "1")  # these tools drive the test / bench surface (mint_amd/_lib.py)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,7 @@
 """The split-K atomic GEMM of the small-batch AR sampler (M = 360 rows) as a function of the K split: what does the
 12.7 us launch consist of?  Weights rotated over 16 copies (a frame streams 16 layers of weights: no L2 reuse).
 python tools/skinny_bench.py"""
+import os as _os; _os.environ.setdefault("FACT_DEBUG_ABI", "1")  # these tools drive the test / bench surface (mint_amd/_lib.py)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -7,6 +7,7 @@ Counter collection serialises the dispatches, so cycles (GRBM_GUI_ACTIVE / 8 XCD
 duration in shader clocks, not its contention-stretched in-step duration.  HBM bytes follow
 MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB, collected in separate passes, and the
 gfx950 FETCH_SIZE is doubled for wide coalesced streams."""
+import os as _os; _os.environ.setdefault("FACT_DEBUG_ABI", "1")  # these tools drive the test / bench surface (mint_amd/_lib.py)
 import collections
 import glob
 import sqlite3
