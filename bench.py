@@ -203,6 +203,14 @@ def kernel_table(model, step_fn, nsteps):
                        frac=round(gbs / PEAK_HBM_GBS, 4), bytes_per_launch=r["bytes"] / r["launches"])
         rows.append(row)
     rows.sort(key=lambda x: -x["time_share"])
+    prof, src = rocprof_symbol_table()
+    for row in rows:  # both clocks side by side (see rocprof_symbol_table)
+        row["clock"] = "engine event recorder"
+        first = row["kernel"].split(" + ")[0]
+        hit = [v for k, v in prof.items() if k.startswith(first) or first.startswith(k)]  # (the summary truncates long symbols)
+        if len(hit) == 1:
+            row["rocprofv3_avg_us_same_symbol"] = hit[0]
+            row["rocprofv3_source"] = src
     return rows, tot / nsteps
 
 
@@ -246,6 +254,25 @@ def wgrad_standalone(device, K=5760, d=800, ff=3072, iters=20):
     tf = flop / us / 1e6
     return {"what": "one launch of all 190 tiles of a cross-modal layer (86.1 GFLOP), alone on the chip",
             "avg_launch_us": round(us, 2), "achieved": round(tf, 1), "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}
+
+
+def rocprof_symbol_table():
+    """Average kernel durations by symbol from the newest committed `rocprofv3 --kernel-trace --stats` summary of this very
+    command (profiles/rNN_kernel_stats_bench_n1.txt): the SECOND clock beside the engine's event recorder.  The recorder
+    brackets a launch with HIP events on its stream and so includes the launch gap (~2-3 us more per launch than the
+    profiler's begin-to-end kernel time); a symbol that serves several classes (the 256x160 bf16 GEMM runs both N = 800
+    dgrads) carries one average for all of them.  Returns ({symbol: avg_us}, file name)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*_kernel_stats_bench_n1.txt")))
+    if not files:
+        return {}, None
+    tab = {}
+    for line in open(files[-1]):
+        m = re.match(r"^(.*\S)\s+(\d+)\s+([\d.]+)\s+([\d.]+)\s+([\d.]+)\s*$", line.rstrip("\n"))
+        if m:
+            tab[m.group(1).strip()] = float(m.group(4))
+    return tab, os.path.basename(files[-1])
 
 
 def measured_traffic(name):
@@ -695,6 +722,9 @@ def main():
                            "time_share": top["time_share"],
                            "flop_per_launch": top.get("flop_per_launch"), "cu_share": top.get("cu_share"),
                            "frac_of_held_cus": top.get("frac_of_held_cus"), "traffic": traffic, "traffic_source": src,
+                           "clock": "engine event recorder (HIP events on the launch stream; ~2-3 us per launch above the "
+                                    "rocprofv3 kernel duration of the same dispatch, given beside it when the symbol is unique)",
+                           "rocprofv3_avg_us_same_symbol": top.get("rocprofv3_avg_us_same_symbol"),
                            "how": "HIP events on the launch stream around every launch of the class, inside normal "
                                   "train steps (all streams overlapping); sum of kernel-class time per step "
                                   "%.2f ms vs %.2f ms wall" % (ksum_ms, ms_per_step)}
