@@ -1495,9 +1495,13 @@ int notify_grads(FactHandle* h, hipStream_t s) {
     // updated together when the LAST cross-modal bucket is final: the HBM-bound update then runs beside
     // the two small encoder stacks' backward, which leaves most of the chip idle.  The encoder buckets
     // follow as they complete.
+    // adam_hold = k >= 1: the release point is the bucket of cross layer k - 1 (k = 1: the last one, layer 0 - whose wgrad
+    // batch is only flushed when the chain has ended, i.e. the update starts ~0.3 ms into the tail; k = 2: layer 1, final
+    // about when the chain ends - the last cross bucket then follows on its own like the encoder buckets)
     const int last_cross = h->cross.L;  // bucket 0 = head, 1..L = cross layers L-1..0
-    if (h->adam_hold && b < last_cross) return 0;
-    const int first = (h->adam_hold && b == last_cross) ? 0 : b;
+    const int release = h->adam_hold ? std::max(0, last_cross - (h->adam_hold - 1)) : 0;
+    if (h->adam_hold && b < release) return 0;
+    const int first = (h->adam_hold && b == release) ? 0 : b;
     stream_after(h, s, h->opt);
     if (side_of(h, s) != s) stream_after(h, h->side, h->opt);
     for (int i = first; i <= b; ++i) CHK(adam_bucket(h, i, h->opt));

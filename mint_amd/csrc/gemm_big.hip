@@ -688,6 +688,26 @@ DEVINL unsigned fastdiv(unsigned x, unsigned magic) { return __umulhi(x, magic);
 // of the launch).  Staging rows carry one 16-byte pad chunk (conflict-free ds_write_b128, 2-way
 // ds_write_b64, linear ds_read_b128).
 // -------------------------------------------------------------------------------------------------
+// 16-byte global store of an epilogue row chunk.  BIG_EPI_WT (A/B build knob, tools/build_variant.sh): 0 = plain store
+// (the line stays - dirty - in the XCD's write-back L2 until it is evicted or the kernel ends: every launch of this
+// family ends with the write-back of whatever part of its 9-70 MB of output is still in the 32 MB of L2, and the next,
+// dependent launch waits for it); 1 = write-through (sc1: the line leaves L2 with the store); 2 = non-temporal.
+#ifndef BIG_EPI_WT
+#define BIG_EPI_WT 0
+#endif
+template <typename V>
+DEVINL void st_out16(void* p, V v) {
+  static_assert(sizeof(V) == 16, "16-byte chunk");
+#if BIG_EPI_WT == 1
+  const u32x4 w = __builtin_bit_cast(u32x4, v);
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
+#elif BIG_EPI_WT == 2
+  __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
+#else
+  *reinterpret_cast<V*>(p) = v;
+#endif
+}
+
 template <int EPI>
 constexpr bool kStagedBf16 = (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD || EPI == EPI_HEADS);
 template <int EPI>
@@ -886,12 +906,12 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
               const unsigned h = fastdiv(rem, ep.mg_dh), d = rem - h * ep.dh;
               const unsigned b = fastdiv(row, ep.mg_ntok), t = row - b * ep.n_tok;
               bf16_t* hr = (which == 0) ? h0 : (which == 1) ? h1 : h2;
-              if (hr) *reinterpret_cast<bf16x8*>(hr + ((size_t)(b * ep.heads + h) * ep.n_pad + t) * ep.dhp + d) = v0;
+              if (hr) st_out16(hr + ((size_t)(b * ep.heads + h) * ep.n_pad + t) * ep.dhp + d, v0);
             } else {
-              if (NOUT == 1 || ep.out0) *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v0;
+              if (NOUT == 1 || ep.out0) st_out16((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col, v0);
               if constexpr (NOUT == 2) {
                 const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + REG + lr * STR + ch * 16);
-                *reinterpret_cast<bf16x8*>((bf16_t*)ep.out1 + (size_t)row * ep.ldo1 + col) = v1;
+                st_out16((bf16_t*)ep.out1 + (size_t)row * ep.ldo1 + col, v1);
               }
             }
           }
@@ -953,7 +973,7 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
             if constexpr (EPI == EPI_F32_BIAS_RESID) {
               v.x += rv[it].x; v.y += rv[it].y; v.z += rv[it].z; v.w += rv[it].w;
             }
-            *reinterpret_cast<float4*>((float*)ep.out0 + (size_t)row * ep.ldo0 + col) = v;
+            st_out16((float*)ep.out0 + (size_t)row * ep.ldo0 + col, v);
           }
         }
       }
