@@ -43,7 +43,7 @@ int fact_kprof_kernels(FactHandle* h, int cls, char* buf, int cap);
  *   "fuse_adam_cast" 1 = Adam writes the bf16 weight shadows itself, 0 = Adam, then a cast/transpose pass
  *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "ln_cs", "bwd_splitk", "adam_hold", "ln_fuse", "lite_stream", "keep_pre":
  *                    scheduling / fusion switches of the A/B runs documented in DESIGN.md sections 3 and 6
- *   "tn_loop", "attn_variant", "adam_variant", "big_impl", "tile192", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on
+ *   "tn_loop", "attn_variant", "adam_variant", "big_impl", "tile192", "sk_sym", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on
  *                    64-deep ring slots; default 3): PROCESS-WIDE kernel selection
  *   "skip":          TIMING-ONLY ablation mask: results are WRONG while it is set */
 int fact_debug_set_option(FactHandle* h, const char* key, int value);
@@ -106,6 +106,9 @@ int fact_debug_attn_timestamps(void* buf);
 int fact_debug_cu_hog(int nwg, int micros, void* stream);
 /* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 6 / 7 = big-tile 288x256 / 256x256). */
 int fact_debug_gemm_splitk_max(int v); /* in-kernel split-K slices of the N = 800 GEMMs (1 = off, default 4) */
+/* 0 = never finish a 2-way in-kernel split-K symmetrically (both slices resident, each runs the epilogue of half the rows;
+ * gemm.h GemmParams::sk_sym), 1 = where the caller allows it and the launch fits the chip (default).  Process-wide. */
+int fact_debug_gemm_sk_sym(int v);
 int fact_debug_gemm_tn_cfg(int v); /* grouped wgrad tile: 0 = 160x256, 1 = 160x384 */
 int fact_debug_gemm_big_impl(int v); /* 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel */
 int fact_debug_gemm_nt_variant(int v);

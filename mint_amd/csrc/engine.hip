@@ -1004,6 +1004,10 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
     g.ep.out0 = a.x_out; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = a.x_mid; g.ep.ldr = d;
     with_ws(h, g, s);
     with_skinny_fwd(h, g, s);
+    // symmetric split-K finish (gemm.h GemmParams::sk_sym): the cross-modal stack's forward is the only work in flight on
+    // the device (the two encoder streams were joined before it, model_forward_hidden), so its 2 x 115 workgroups are
+    // co-resident; the encoder stacks run side by side and keep the exiting finish
+    g.sk_sym = (&st == &h->cross) ? 1 : 0;
     if (l + 1 < st.L && st.la[l + 1].x_in == a.x_out) {  // LayerNorm 1 of the next layer of this stack
       LayerP& pn = st.lp[l + 1];
       LayerA& an = st.la[l + 1];
@@ -1810,6 +1814,10 @@ int fact_debug_set_option(FactHandle* h, const char* key, int value) {
     gemm_set_k64(value);
     return 0;
   }
+  if (!strcmp(key, "sk_sym")) {  // process-wide: 0 = never the symmetric 2-way split-K finish of the cross-modal FFN2 GEMM
+    gemm_set_sk_sym(value);
+    return 0;
+  }
   if (!strcmp(key, "tile192")) {  // process-wide: 192x160 tiles for the whole-K N = 800 dgrads
     gemm_set_tile192(value);
     return 0;
@@ -2274,6 +2282,7 @@ int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int
     }
     g.sk_slab = slab;
     g.sk_cnt = cnt;
+    g.sk_sym = 1;  // the op runs alone on the device (tests, benches): symmetric 2-way finish where the dispatcher allows it
   }
   CHK(launch_gemm_nt(epi, g, (hipStream_t)stream));
   return 0;
@@ -2356,6 +2365,10 @@ int fact_debug_gemm_tn_cfg(int v) {  // low byte: main loop (0 staggered, 1 / 2 
 }
 int fact_debug_gemm_splitk_max(int v) {
   gemm_set_splitk_max(v);
+  return 0;
+}
+int fact_debug_gemm_sk_sym(int v) {
+  gemm_set_sk_sym(v);
   return 0;
 }
 int fact_debug_gemm_big_impl(int v) {

@@ -893,6 +893,8 @@ int band_for(int tiles, int tm, int bm, int bn) {
   return band;
 }
 
+int g_sk_sym = 1;  // A/B knob (gemm_set_sk_sym): 0 = never the symmetric 2-way split-K finish
+
 template <int EPI>
 int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
@@ -964,6 +966,15 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
       // pays from ~24 stages (768 k) per slice - K = 3072 / 2400 yes, K = 800 no
       while (sk > 1 && (p.K / 32) / sk < 24) --sk;
       if (sk > 1) p.splitk = sk;
+      // symmetric finish: every workgroup of the launch must be resident at once (one per CU: 156 KiB of LDS each)
+      static const int n_cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
+      }();
+      if (!(sk == 2 && g_sk_sym && t160 * 2 <= n_cus)) p.sk_sym = 0;
+    } else {
+      p.sk_sym = 0;
     }
     if (cfg >= 0 && (EPI != EPI_HEADS || (p.M < 65536 && p.N < 65536))) {
       int bm = 0, bn = 0;
@@ -1029,6 +1040,7 @@ void gemm_set_tile192(int v) { g_tile192 = v; }
 void gemm_set_big_impl(int v) { g_big_impl = v; }
 void gemm_set_k64(int v) { g_k64 = v; }
 void gemm_set_splitk_max(int v) { g_splitk_max = v < 1 ? 1 : (v > 4 ? 4 : v); }
+void gemm_set_sk_sym(int v) { g_sk_sym = v; }
 void gemm_set_nt_band(int band) { g_nt_band = band; }
 
 // K split of the skinny-M path, 0 = the GEMM does not take it

@@ -772,6 +772,9 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
   if constexpr (C::KS == 64) big_mainloop64<C, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
   else big_mainloop<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
 
+  // rows of the wave tile this workgroup runs the epilogue for: all (-1), or - symmetric 2-way split-K finish - the
+  // accumulator rows i < MR / 2 (0) or i >= MR / 2 (1)
+  int epi_half = -1;
   if (p.splitk > 1) {
     // In-launch split-K finish (cdna_hip_programming.md 5 "in-launch split-K reduction", write-through form):
     // every slice publishes its fp32 partial tile with sc1 (write-through) 16-byte stores in fragment order
@@ -779,38 +782,52 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     // slice that draws the last ticket adds its peers' partials (sc1 loads behind one agent-scope acquire)
     // and runs the epilogue.  No spinning: an early slice exits.  Placement-independent; the counter is
     // returned to zero by the last arriver.
+    //
+    // SYMMETRIC finish (round 5; GemmParams::sk_sym, 2 slices, fp32 + residual epilogue).  A CU streams ~25 GB/s from / to
+    // HBM whatever it does, so the finish above runs at what HALF the launch's CUs can pull: the last arriver of each tile
+    // reads its peer's 164 KB partial, the 82 KB residual rows and writes 164 KB... while the other slice's CU has already
+    // left.  Here both slices stay: each publishes only the accumulator rows the OTHER one finishes (i >= MR / 2 from
+    // slice 0, i < MR / 2 from slice 1: half the slab traffic), waits for its peer's half (bounded spin on the arrival
+    // counter - the two slices of a tile are neighbouring ids of one launch of <= #CUs one-per-CU workgroups, i.e.
+    // co-resident; the host only sets the flag then), adds it and runs the epilogue passes of its own rows.  Counter:
+    // +1 on arrival (wait for >= 2), +1 when the peer's data has been read; the 4th increment returns it to zero.
     constexpr unsigned WG_BYTES = (unsigned)BM * BN * 4;
     char* tile_slabs = reinterpret_cast<char*>(p.sk_slab) + (size_t)tile * p.splitk * WG_BYTES;
     const unsigned lane_off = (unsigned)(wave * MR * NR * 1024 + lane * 16);
+    constexpr bool SYM_OK = kStagedF32<EPI> && (MR % 2 == 0) &&
+                            (C::NW * (MR / 2) * 16 * (NR * 64 + 16) <= C::LDS_BYTES);  // epilogue passes of <= MR / 2 rows
+    const bool sym = SYM_OK && p.sk_sym && p.splitk == 2;
     {
       const __amdgpu_buffer_rsrc_t mine =
           __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)z * WG_BYTES, 0, WG_BYTES, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < MR; ++i)
+      for (int i = 0; i < MR; ++i) {
+        if (sym && ((i >= MR / 2) != (z == 0))) continue;  // (wave-uniform) only the rows the peer will finish
 #pragma unroll
         for (int j = 0; j < NR; ++j)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), mine,
                                                  lane_off + (i * NR + j) * 1024, 0, /*sc1*/ 16);
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle: no second __shared__ object
-    if (tid == 0)
-      *flag = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const unsigned ticket = *flag;
-    if (ticket != (unsigned)(p.splitk - 1)) return;
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    for (int zz = 0; zz < p.splitk; ++zz) {
-      if (zz == z) continue;
+    if (sym) {
+      if (tid == 0) {
+        __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(p.sk_cnt + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > (1u << 26)) __builtin_trap();  // a peer that never arrives is a launch-geometry bug: fail, do not hang
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
       const __amdgpu_buffer_rsrc_t peer =
-          __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)zz * WG_BYTES, 0, WG_BYTES, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)(1 - z) * WG_BYTES, 0, WG_BYTES, 0x00020000);
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
+        if ((i >= MR / 2) != (z == 1)) continue;  // my rows: i < MR / 2 for slice 0
         u32x4 t[NR];
 #pragma unroll
         for (int j = 0; j < NR; ++j)
@@ -818,8 +835,39 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
 #pragma unroll
         for (int j = 0; j < NR; ++j) acc[i][j] += __builtin_bit_cast(f32x4, t[j]);
       }
+      __syncthreads();  // every wave holds its peer data (the loads above were waited for by the adds)
+      if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == 3u) __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      epi_half = z;
+    } else {
+      if (tid == 0)
+        *flag = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const unsigned ticket = *flag;
+      if (ticket != (unsigned)(p.splitk - 1)) return;
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      for (int zz = 0; zz < p.splitk; ++zz) {
+        if (zz == z) continue;
+        const __amdgpu_buffer_rsrc_t peer =
+            __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)zz * WG_BYTES, 0, WG_BYTES, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+          u32x4 t[NR];
+#pragma unroll
+          for (int j = 0; j < NR; ++j)
+            t[j] = __builtin_amdgcn_raw_buffer_load_b128(peer, lane_off + (i * NR + j) * 1024, 0, /*sc1*/ 16);
+#pragma unroll
+          for (int j = 0; j < NR; ++j) acc[i][j] += __builtin_bit_cast(f32x4, t[j]);
+        }
+      }
+      __syncthreads();  // flag word read by everyone before the ring is reused as epilogue staging
     }
-    __syncthreads();  // flag word read by everyone before the ring is reused as epilogue staging
   }
 
   const EpiParams& ep = p.ep;
@@ -934,6 +982,9 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
       unsigned char* stg = smem + wave * REG;
 #pragma unroll
       for (int c = 0; c < MR / CH; ++c) {
+        // symmetric split-K finish: only the passes of this slice's accumulator rows (CH <= MR / 2 there: a pass never
+        // straddles the halves)
+        if (epi_half >= 0 && ((c * CH >= MR / 2) != (epi_half == 1))) continue;
         const int prow0 = wrow0 + c * CH * 16;
         // the fp32 residual rows of this pass are requested first, whole row segments per wave load; their
         // latency hides behind the accumulator -> LDS re-shape below
@@ -981,10 +1032,12 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     }
   }
 #pragma unroll
-  for (int i = 0; i < MR; ++i)
+  for (int i = 0; i < MR; ++i) {
+    if (epi_half >= 0 && ((i >= MR / 2) != (epi_half == 1))) continue;
 #pragma unroll
     for (int j = 0; j < NR; ++j)
       direct_store<EPI>(ep, p.M, p.N, wrow0 + i * 16 + (lane & 15), wcol0 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+  }
 }
 
 // One lane's share of the un-staged epilogue: output row `row`, columns col0..col0+3 (col0 % 4 == 0).

@@ -178,6 +178,39 @@ def test_gemm_nt_splitk_in_kernel(M, N, K):
     _close(o1, o2, 1e-5, 1e-4, "split vs unsplit")
 
 
+@pytest.mark.parametrize("M,N,K", [(5760, 800, 3072), (5632, 800, 3072), (4000, 800, 1600), (5760, 800, 1600)])
+def test_gemm_nt_splitk_symmetric_finish(M, N, K):
+    """Round 5: 2-way in-kernel split-K whose two slices BOTH stay and each run the fp32 epilogue of half the tile's rows
+    (gemm.h GemmParams::sk_sym) against the exiting finish (last arriver does everything).  Each output element is
+    own-partial + peer-partial in either form - fp32 addition commutes - so the two must agree BIT FOR BIT, bias and
+    residual included; checked over many back-to-back launches with fresh operands (arrival counter returns to zero,
+    no stale slab line), with a ragged last row tile (5760 = 22.5 x 256, 4000 = 15.6 x 256) and against torch.  (Every
+    shape here splits 2 ways; a 3- or 4-way split keeps the exiting finish, whose summation order follows the arrival
+    order and is not reproducible bit for bit.)"""
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(23)
+    bias = torch.randn(N, device=DEV, generator=g)
+    for it in range(6):
+        A = _bf(torch.randn(M, K, device=DEV, generator=g))
+        B = _bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
+        resid = torch.randn(M, N, device=DEV, generator=g)
+        outs = []
+        for sym in (1, 0, 1):
+            lib.fact_debug_gemm_sk_sym(sym)
+            try:
+                o = torch.full((M, N), float("nan"), device=DEV)
+                _gemm_nt(L.EPI_F32_BIAS_RESID, A, B, M, N, K, o, bias=bias, resid=resid)
+            finally:
+                lib.fact_debug_gemm_sk_sym(1)
+            outs.append(o)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "it %d: symmetric vs exiting finish" % it
+        _close(outs[0], A.float() @ B.float().t() + bias + resid, 1e-4, 2e-3, "symmetric finish it%d" % it)
+        if it == 3:  # a bf16-epilogue launch in between (exiting finish, same counters and slabs)
+            o16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            _gemm_nt(L.EPI_BF16, A, B, M, N, K, o16)
+            _close(o16, A.float() @ B.float().t(), 1e-2, 1e-2 * math.sqrt(K) * 0.1, "bf16 between symmetric launches")
+
+
 @pytest.mark.parametrize("M,N,K", [(5760, 800, 3072), (5760, 800, 2400), (700, 800, 800), (300, 500, 96), (256, 160, 32),
                                    (257, 161, 64), (1920, 800, 3072), (64, 72, 160)])
 @pytest.mark.parametrize("variant", [17, 18, 19], ids=["256x160", "288x256", "256x256"])
