@@ -742,7 +742,7 @@ def test_adam_in_wgrad_matches_bucket_optimizer(cfg_name, B, T, sr, continuous_a
     lr = 1e-3
     ref1 = _train_state(cfg, B, T, 1, 0, lr=lr, sr_rows=sr)
     got1 = _train_state(cfg, B, T, 1, 1, lr=lr, sr_rows=sr)
-    assert got1[0] == pytest.approx(ref1[0], rel=2e-5)
+    assert got1[0] == pytest.approx(ref1[0], rel=5e-4)  # (same weights: what differs is the split-K atomic order of the forward)
     # moments = linear / quadratic in the gradient.  Two runs of ONE path differ by ~1e-3 relative in single gradient
     # elements at the fact_v5 dimensions (a 1-ulp difference from the split-K atomics of the supervised-rows layer flips a
     # bf16 rounding downstream): Frobenius-level agreement, and no element off by more than a few percent of the scale
