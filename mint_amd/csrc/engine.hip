@@ -2052,6 +2052,7 @@ int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps
   h->adam.b2 = beta2;
   h->adam.eps = eps;
   h->adam.gscale = 1.0f;
+  h->wg_adam = false;  // decided per fact_forward_backward call (a call that failed half-way must not leave it set)
   // created on first use, and only when the engine itself will enqueue the updates (with a gradient callback the
   // host calls fact_adam_bucket on its communication stream: one stream less competing for the hardware queues)
   if (!h->opt && !h->cb) HIPCHK(make_stream(&h->opt, "FACT_PRIO_OPT"));
@@ -2077,6 +2078,7 @@ int fact_adam_cancel(FactHandle* h) {
     h->adam_pending = false;
     h->step -= 1;
   }
+  h->wg_adam = false;
   return 0;
 }
 
