@@ -43,7 +43,7 @@ int fact_kprof_kernels(FactHandle* h, int cls, char* buf, int cap);
  *   "fuse_adam_cast" 1 = Adam writes the bf16 weight shadows itself, 0 = Adam, then a cast/transpose pass
  *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "ln_cs", "bwd_splitk", "adam_hold", "ln_fuse", "lite_stream", "keep_pre":
  *                    scheduling / fusion switches of the A/B runs documented in DESIGN.md sections 3 and 6
- *   "tn_loop", "attn_variant", "adam_variant", "big_impl", "tile192", "sk_sym", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on
+ *   "tn_loop", "attn_variant", "adam_variant", "big_impl", "tile192", "tile128x160", "sk_sym", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on
  *                    64-deep ring slots; default 3): PROCESS-WIDE kernel selection
  *   "skip":          TIMING-ONLY ablation mask: results are WRONG while it is set */
 int fact_debug_set_option(FactHandle* h, const char* key, int value);

@@ -1818,6 +1818,10 @@ int fact_debug_set_option(FactHandle* h, const char* key, int value) {
     gemm_set_sk_sym(value);
     return 0;
   }
+  if (!strcmp(key, "tile128x160")) {  // process-wide: short-K N = 800 GEMMs on 128x160 tiles (225 workgroups at M = 5760)
+    gemm_set_tile128x160(value);
+    return 0;
+  }
   if (!strcmp(key, "tile192")) {  // process-wide: 192x160 tiles for the whole-K N = 800 dgrads
     gemm_set_tile192(value);
     return 0;

@@ -84,7 +84,8 @@ constexpr int kSplitKCounters = 1024;
 // ---- big-tile family (gemm_big.hip): one 8-wave workgroup per CU, 4-deep LDS-DMA ring -------------------
 enum BigCfgId : int { BIG_288x256 = 0, BIG_256x256 = 1, BIG_256x160 = 2, BIG_160x256 = 3, BIG_256x128 = 4,
                       BIG_256x160_K64 = 5, BIG_288x256_K64 = 6, BIG_256x256_K64 = 7 /* 64-deep ring slots (whole-line DMA pieces) */,
-                      BIG_192x160_K64 = 8 /* round 4: 150 instead of 115 tiles for the whole-K N = 800 dgrads at M = 5760 */ };
+                      BIG_192x160_K64 = 8 /* round 4: 150 instead of 115 tiles for the whole-K N = 800 dgrads at M = 5760 */,
+                      BIG_128x160 = 9 /* round 5: short-K N = 800 GEMMs as 225 tiles, two workgroups per CU */ };
 int big_tile_dims(int cfg, int* bm, int* bn);
 // NT GEMM on a given tile config (K % 32 == 0, splitk == 1); fused epilogues as above.
 int launch_big_nt(int cfg, int epi, const GemmParams& p, hipStream_t stream);
@@ -139,6 +140,7 @@ void gemm_set_nt_variant(int v);  // 0 auto, 1 = 128x128, 6 / 7 = round-1 big ti
 void gemm_set_tile192(int v);     // auto mode: 1 = 192x160 tiles for the whole-K N = 800 dgrads (BIG_192x160_K64)
 void gemm_set_k64(int v);         // auto mode: 1 = 256x160 GEMMs run on 64-deep ring slots (BIG_256x160_K64)
 void gemm_set_big_impl(int v);    // auto mode: 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel
+void gemm_set_tile128x160(int v);  // auto mode: 1 (default) = 128x160 tiles (two workgroups per CU) for the short-K N = 800 GEMMs, 0 = 256x128
 void gemm_set_sk_sym(int v);      // 0 = never the symmetric 2-way split-K finish (GemmParams::sk_sym), 1 = when asked for (default)
 void gemm_set_splitk_max(int v);  // in-kernel split-K of the 256x160 tile: max slices (default 4, 1 = off)
 void gemm_set_nt_band(int band);   // NT tile band height (1 = row-major)

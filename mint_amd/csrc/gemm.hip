@@ -894,6 +894,11 @@ int band_for(int tiles, int tm, int bm, int bn) {
 }
 
 int g_sk_sym = 1;  // A/B knob (gemm_set_sk_sym): 0 = never the symmetric 2-way split-K finish
+// short-K N = 800 GEMMs (out-projection forward / dgrad) on 128x160 instead of 256x128 tiles, two workgroups per CU either way:
+// 45 x 5 = 225 workgroups instead of 23 x 7 = 161 (with 12.5 % column padding) at M = 5760, so the epilogue streams from 225
+// CUs.  Round 5: stand-alone 21.2 -> 18.8 us (+ residual), 14.3 -> 13.1 us (bf16); in the step 26.0 -> 25.0 and 28.2 -> 25.6 us
+// per launch, step 7.574 -> 7.525 ms (3 interleaved rounds, profiles/r05_ab_tile128x160.txt).  0 = the round-2 tile (A/B knob)
+int g_tile128x160 = 1;
 
 template <int EPI>
 int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
@@ -949,6 +954,10 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
     if (variant == 18) cfg = k64_ok ? BIG_288x256_K64 : BIG_288x256;
     if (variant == 19) cfg = k64_ok ? BIG_256x256_K64 : BIG_256x256;
     if (variant == 20) cfg = BIG_192x160_K64;
+    if (variant == 21) cfg = BIG_128x160;
+    if (variant == 0 && g_tile128x160 && cfg == BIG_256x128 && p.N % 160 == 0 && p.N <= 960 &&
+        (EPI == EPI_F32_BIAS_RESID || EPI == EPI_HEADS || EPI == EPI_BF16))
+      cfg = BIG_128x160;  // A/B knob: the short-K N = 800 GEMMs on 128x160 tiles
     if (g_k64 && variant == 0 && k64_ok) {
       if (cfg == BIG_256x160 && EPI == EPI_BF16 && g_tile192 && !ws && p.M % 192 == 0 && (p.M / 192) * ((p.N + 159) / 160) <= 256)
         cfg = BIG_192x160_K64;  // the whole-K dgrads of the backward chain: more, smaller tiles in the one round they get
@@ -1041,6 +1050,7 @@ void gemm_set_big_impl(int v) { g_big_impl = v; }
 void gemm_set_k64(int v) { g_k64 = v; }
 void gemm_set_splitk_max(int v) { g_splitk_max = v < 1 ? 1 : (v > 4 ? 4 : v); }
 void gemm_set_sk_sym(int v) { g_sk_sym = v; }
+void gemm_set_tile128x160(int v) { g_tile128x160 = v; }
 void gemm_set_nt_band(int band) { g_nt_band = band; }
 
 // K split of the skinny-M path, 0 = the GEMM does not take it

@@ -1434,6 +1434,10 @@ using Cfg256x256k64 = BigCfg<2, 8, 4, 4, 2, 1, 64>;  // 2 x 64 KiB
 // N = 800 dgrads of the backward chain run ONE round beside the 95-workgroup wgrad launch either way, so 25 % less work per
 // tile is 15-20 % less kernel (13 % more operand bytes per FLOP)
 using Cfg192x160k64 = BigCfg<4, 3, 2, 5, 3, 1, 64>;
+// 128x160 (wave tile 32 x 80), 3 x 18 KiB slots, two workgroups per CU: 45 x 5 = 225 tiles for M = 5760, N = 800 - the fp32 +
+// residual epilogue of the K = 800 out-projection then streams from 225 CUs instead of 161 (nt variant 21; default for the
+// short-K N = 800 GEMMs since round 5, gemm.hip g_tile128x160)
+using Cfg128x160 = BigCfg<4, 2, 2, 5, 3, 2>;
 
 template <int EPI>
 int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
@@ -1447,6 +1451,9 @@ int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
     case BIG_256x256_K64: return launch_big_nt_cfg<Cfg256x256k64, EPI>(p, s);
     case BIG_192x160_K64:
       if constexpr (EPI == EPI_BF16) return launch_big_nt_cfg<Cfg192x160k64, EPI>(p, s);  // the dgrad epilogue only
+      else return -7;
+    case BIG_128x160:
+      if constexpr (EPI == EPI_F32_BIAS_RESID || EPI == EPI_HEADS || EPI == EPI_BF16) return launch_big_nt_cfg<Cfg128x160, EPI>(p, s);
       else return -7;
   }
   return -7;
@@ -1467,6 +1474,7 @@ int big_tile_dims(int cfg, int* bm, int* bn) {
     case BIG_288x256_K64: *bm = 288; *bn = 256; return 0;
     case BIG_256x256_K64: *bm = 256; *bn = 256; return 0;
     case BIG_192x160_K64: *bm = 192; *bn = 160; return 0;
+    case BIG_128x160: *bm = 128; *bn = 160; return 0;
   }
   return -1;
 }
@@ -1474,7 +1482,7 @@ int big_tile_dims(int cfg, int* bm, int* bn) {
 int launch_big_nt(int cfg, int epi, const GemmParams& p_in, hipStream_t s) {
   GemmParams p = p_in;
   if (p.K % 32 || p.K < 32 || p.splitk < 1 || p.splitk > 4) return -6;
-  if (cfg >= BIG_256x160_K64 && (p.lda < ((p.K + 63) & ~63) || p.ldb < ((p.K + 63) & ~63) || (p.lda & 7) || (p.ldb & 7))) return -6;
+  if (cfg >= BIG_256x160_K64 && cfg != BIG_128x160 && (p.lda < ((p.K + 63) & ~63) || p.ldb < ((p.K + 63) & ~63) || (p.lda & 7) || (p.ldb & 7))) return -6;
   if ((size_t)p.M * p.lda >= (1ull << 31) || (size_t)p.N * p.ldb >= (1ull << 31)) return -6;  // 32-bit lane offsets
   if (epi == EPI_HEADS) {
     if (p.M >= 65536 || p.N >= 65536) return -8;

@@ -265,6 +265,30 @@ def test_gemm_nt_tile192(M, N, K):
     assert _rel_err(out, ref) < 4e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(5760, 800, 800), (3840, 800, 800), (577, 260, 192), (128, 160, 32)])
+def test_gemm_nt_tile128x160(M, N, K):
+    """The 128x160 tile (round 5, two workgroups per CU, 225 tiles at M = 5760 / N = 800; the engine's choice for the
+    out-projection forward / dgrad): the bf16 and the fp32 + bias + residual epilogues, forced on full, encoder-sized and
+    ragged shapes (the per-head scatter epilogue on this tile is covered by the attention and model tests)."""
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(14)
+    A = _bf(torch.randn(M, K, device=DEV, generator=g))
+    B = _bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
+    bias = torch.randn(N, device=DEV, generator=g)
+    resid = torch.randn(M, N, device=DEV, generator=g)
+    ref = A.float() @ B.float().t()
+    lib.fact_debug_gemm_nt_variant(21)
+    try:
+        o16 = torch.full((M, N), float("nan"), device=DEV, dtype=torch.bfloat16)
+        _gemm_nt(L.EPI_BF16, A, B, M, N, K, o16)
+        o32 = torch.full((M, N), float("nan"), device=DEV)
+        _gemm_nt(L.EPI_F32_BIAS_RESID, A, B, M, N, K, o32, bias=bias, resid=resid)
+    finally:
+        lib.fact_debug_gemm_nt_variant(0)
+    _close(o16, ref, 1e-2, 1e-2 * math.sqrt(K) * 0.1, "gemm_nt 128x160 bf16")
+    _close(o32, ref + bias + resid, 1e-4, 2e-3, "gemm_nt 128x160 resid")
+
+
 def test_gemm_nt_epilogues(nt_variant):
     M, N, K, seq = 480, 800, 256, 120
     g = torch.Generator(device=DEV).manual_seed(2)

@@ -162,6 +162,10 @@ if __name__ == "__main__":
             nt_case(Me, 3072, 800, L.EPI_GELU_BWD, [1, 10, 11, 14], "enc gelu'")
             nt_case(Me, 800, 3072, L.EPI_BF16, [1, 12, 14], "enc dFFN1")
             nt_case(Me, 800, 2400, L.EPI_BF16, [1, 12, 14], "enc dQKV")
+    if what == "t128":  # short-K N = 800 GEMMs: 256x128 x 2 per CU (v14, shipped) vs 128x160 x 2 per CU (v21, round-5 probe)
+        for M in (5760, 3840, 1920):
+            nt_case(M, 800, 800, L.EPI_F32_BIAS_RESID, [14, 21, 14, 21], "out-proj+resid")
+            nt_case(M, 800, 800, L.EPI_BF16, [14, 21, 14, 21], "N800 K800 bf16")
     if what == "k64":  # 256x160 tiles: 32-deep (v12, v112 = without split-K) vs 64-deep ring slots (v17, v117 = without split-K)
         M = 5760
         for rep in range(2):
