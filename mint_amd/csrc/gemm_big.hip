@@ -1438,6 +1438,9 @@ using Cfg192x160k64 = BigCfg<4, 3, 2, 5, 3, 1, 64>;
 // residual epilogue of the K = 800 out-projection then streams from 225 CUs instead of 161 (nt variant 21; default for the
 // short-K N = 800 GEMMs since round 5, gemm.hip g_tile128x160)
 using Cfg128x160 = BigCfg<4, 2, 2, 5, 3, 2>;
+// (the same tile for the LONG-K N = 800 GEMMs, whole K, 225 workgroups: FFN2 + residual 44.9 us against 40.3 us for 256x160
+//  with the symmetric split-K; whole-K dgrads 40.2 vs 42.3 us; on two 64-deep slots 1-4 us slower still -
+//  profiles/r05_tile128x160_long_k.txt.  Not used there.)
 
 template <int EPI>
 int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {

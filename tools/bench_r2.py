@@ -166,6 +166,11 @@ if __name__ == "__main__":
         for M in (5760, 3840, 1920):
             nt_case(M, 800, 800, L.EPI_F32_BIAS_RESID, [14, 21, 14, 21], "out-proj+resid")
             nt_case(M, 800, 800, L.EPI_BF16, [14, 21, 14, 21], "N800 K800 bf16")
+    if what == "t128long":  # long-K N = 800 GEMMs: 256x160 with the (symmetric) in-kernel split-K (v17) vs 128x160 whole-K, 2 per CU (v21)
+        for M in (5760, 3840):
+            nt_case(M, 800, 3072, L.EPI_F32_BIAS_RESID, [17, 21, 17, 21], "FFN2+resid")
+            nt_case(M, 800, 3072, L.EPI_BF16, [117, 21, 117, 21], "dgrad FFN1 (whole K)")
+            nt_case(M, 800, 2400, L.EPI_BF16, [117, 21], "dgrad QKV (whole K)")
     if what == "k64":  # 256x160 tiles: 32-deep (v12, v112 = without split-K) vs 64-deep ring slots (v17, v117 = without split-K)
         M = 5760
         for rep in range(2):
