@@ -735,7 +735,7 @@ def test_adam_in_wgrad_matches_bucket_optimizer(cfg_name, B, T, sr, continuous_a
       * after THREE steps the moments still agree closely; the weights only to a fraction of a step: Adam normalises every
         gradient to ~lr, so wherever a gradient is at noise level the sign of its update follows the atomic order of the
         bias / LayerNorm sums of the step before - two runs of the SAME path differ by up to ~0.2 lr in a third of the
-        weights (measured, tools/runs/r5_adam_diag.py), and that control is the tolerance here;
+        weights (measured, tools/attic/runs/r5_adam_diag.py), and that control is the tolerance here;
       * the fused path was really taken: the layer kernels' gradient-arena ranges stay untouched (zero), everything else in
         the arena is zeroed as before."""
     cfg = GROUPED_CFG if cfg_name == "grouped" else O.FACT_V5_CFG

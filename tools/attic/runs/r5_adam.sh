@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: parity of the optimizer-in-wgrad path, then same-box A/B of the headline step (interleaved, 2 rounds)
-cd "$(dirname "$0")/../.."; R=$(pwd); mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.."; R=$(pwd); mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -k "tn_group" 2>&1 | tail -5 | tee gpurun_out/r5_adam_tests.txt
 timeout 1200 python -m pytest tests/test_gpu_model.py -q -x -k "adam_in_wgrad or fused_optimizer or adam_fused or grad_overwrite or options_survive" 2>&1 | tail -5 | tee -a gpurun_out/r5_adam_tests.txt
 run() {  # $1 = label, rest = bench args

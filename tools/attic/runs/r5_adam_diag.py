@@ -1,8 +1,8 @@
 """Diagnostic: optimizer-in-wgrad vs bucket path, per tensor, after 1 and 2 steps, plus a same-path control."""
 import os, sys
 os.environ.setdefault("FACT_DEBUG_ABI", "1")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))), "tests"))
 import torch
 import test_gpu_model as T
 from mint_amd import _lib as L

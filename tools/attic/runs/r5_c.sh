@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, call C: tests of the changed pieces + upper bound of an LN fusion (timing-only skip ablation) + adam_in_wgrad on configs[4]
-cd "$(dirname "$0")/../.."; mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.."; mkdir -p gpurun_out
 ( timeout 900 python -m pytest tests/test_gpu_model.py tests/test_gpu_production_lib.py -q -x -k "adam_in_wgrad or production" 2>&1 | tail -5
   timeout 900 python -m pytest tests/test_gpu_ops.py -q -x -k "attention" 2>&1 | tail -3 ) | tee gpurun_out/r5_c_tests.txt
 run() { local label=$1; shift

@@ -1,6 +1,6 @@
 #!/bin/bash
 # call D: forward launch boundary (two clocks), write-through epilogue stores A/B, re-run of the adjusted adam test
-cd "$(dirname "$0")/../.."; R=$(pwd); O=$R/gpurun_out; mkdir -p $O
+cd "$(dirname "$0")/../../.."; R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 timeout 900 python -m pytest tests/test_gpu_model.py -q -x -k "adam_in_wgrad" 2>&1 | tail -3 | tee $O/r5_d_tests.txt
 { ITERS=23 python tools/fwd_boundary.py 2>/dev/null | grep FWD_WALL
   cd /tmp && export TMPDIR=/tmp

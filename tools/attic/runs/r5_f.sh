@@ -1,6 +1,6 @@
 #!/bin/bash
 # call F: symmetric split-K finish - op parity, stand-alone FFN2 A/B, step A/B
-cd "$(dirname "$0")/../.."; R=$(pwd); O=$R/gpurun_out; mkdir -p $O
+cd "$(dirname "$0")/../../.."; R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_ops.py -q -x -k "splitk" 2>&1 | tail -4 | tee $O/r5_f_tests.txt
 python - <<'PY' 2>&1 | grep -v amdgpu | tee $O/r5_sksym_standalone.txt
 import os; os.environ.setdefault("FACT_DEBUG_ABI", "1")

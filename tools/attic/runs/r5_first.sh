@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, first GPU call: launch-boundary probe + kernarg placement A/B on the headline step
-cd "$(dirname "$0")/../.."; R=$(pwd); mkdir -p gpurun_out
+cd "$(dirname "$0")/../../.."; R=$(pwd); mkdir -p gpurun_out
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/lf2 tools/launch_floor2.hip
 for v in unset 0 1; do
   echo "== HIP_FORCE_DEV_KERNARG=$v" | tee -a gpurun_out/r5_launch_floor.txt

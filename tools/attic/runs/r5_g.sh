@@ -1,6 +1,6 @@
 #!/bin/bash
 # call G: 128x160 tiles for the short-K N = 800 GEMMs - parity, stand-alone, step A/B; AR 64-frame numbers
-cd "$(dirname "$0")/../.."; R=$(pwd); O=$R/gpurun_out; mkdir -p $O
+cd "$(dirname "$0")/../../.."; R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_ops.py -q -x -k "tile128x160" 2>&1 | tail -3 | tee $O/r5_g_tests.txt
 timeout 300 python tools/bench_r2.py t128 2>/dev/null | grep -v amdgpu | tee $O/r5_t128_standalone.txt
 run() { local label=$1; shift

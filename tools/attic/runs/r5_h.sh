@@ -1,5 +1,5 @@
 #!/bin/bash
-cd "$(dirname "$0")/../.."; R=$(pwd); O=$R/gpurun_out; mkdir -p $O
+cd "$(dirname "$0")/../../.."; R=$(pwd); O=$R/gpurun_out; mkdir -p $O
 timeout 1200 python -m pytest tests/test_gpu_ops.py -q -x 2>&1 | tail -3 | tee $O/r5_h_tests.txt
 timeout 1200 python -m pytest tests/test_gpu_model.py -q -x -k "fact_v5 or headline or tiny_forward or supervised or big_tile" 2>&1 | tail -3 | tee -a $O/r5_h_tests.txt
 run() { local label=$1; shift
