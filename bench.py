@@ -2,7 +2,9 @@
 MFMA compute / fp32 master weights, batch 16 per GPU, AIST++-shaped synthetic tensors).
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N>1: either under a launcher - python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ... -
+   or bare: without WORLD_SIZE in the environment `python bench.py --gpus N` re-executes itself under that launcher,
+   one rank per GPU; every rank checks WORLD_SIZE == --gpus)
 
 A step = one pass of the hot path over one batch: forward, MSE loss on 20 target frames, backward,
 RCCL gradient all-reduce (N>1), Keras-Adam update, bf16 weight-shadow refresh.  Prints ONE JSON line
