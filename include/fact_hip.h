@@ -194,8 +194,8 @@ int fact_set_grad_callback(FactHandle* h, fact_grad_cb cb, void* user, void* com
  *                        the optimizer pass (Keras Adam, single_task_trainer.py:186-187 / trainer.py:150); takes effect
  *                        only when every stack runs the grouped launch (B * seq_len a multiple of 32 and >= 512, widths
  *                        multiples of 16), otherwise the step silently keeps the bucket path.  0 = always the bucket path.
- *                        Pays when the wgrad launches fill the chip; at fact_v5 / batch 16 they are given 95 of 256 CUs
- *                        beside the dgrad chain and the update streams at what 95 CUs can pull.
+ *                        At fact_v5 / batch 16 the wgrad launches are given 95 of 256 CUs beside the dgrad chain and the
+ *                        update streams at half the rate of the 256-CU optimizer kernel: measured slower.
  *   "side_stream"    (default 1) 1 = the weight-gradient batches / the audio encoder run on the handle's second stream
  *   "aux_stream"     (default 1) 1 = the motion encoder's backward chain runs on the handle's third stream; hosts that
  *                        add a communication stream (data parallelism) set 0 to stay within the hardware queues */

@@ -783,9 +783,10 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     // and runs the epilogue.  No spinning: an early slice exits.  Placement-independent; the counter is
     // returned to zero by the last arriver.
     //
-    // SYMMETRIC finish (round 5; GemmParams::sk_sym, 2 slices, fp32 + residual epilogue).  A CU streams ~25 GB/s from / to
-    // HBM whatever it does, so the finish above runs at what HALF the launch's CUs can pull: the last arriver of each tile
-    // reads its peer's 164 KB partial, the 82 KB residual rows and writes 164 KB... while the other slice's CU has already
+    // SYMMETRIC finish (round 5; GemmParams::sk_sym, 2 slices, fp32 + residual epilogue).  The HBM rate a launch gets grows
+    // with the CUs it holds (tools/cu_stream_probe.hip: 115 CUs 4.1-4.8 TB/s, 230 the chip's rate), and the finish above
+    // runs on HALF the launch's CUs: the last arriver of each tile reads its peer's 164 KB partial, the 82 KB residual rows
+    // and writes 164 KB... while the other slice's CU has already
     // left.  Here both slices stay: each publishes only the accumulator rows the OTHER one finishes (i >= MR / 2 from
     // slice 0, i < MR / 2 from slice 1: half the slab traffic), waits for its peer's half (bounded spin on the arrival
     // counter - the two slices of a tile are neighbouring ids of one launch of <= #CUs one-per-CU workgroups, i.e.
