@@ -78,10 +78,30 @@ def maybe_spawn_ranks(argv=None, environ=None, execve=None):
 if __name__ == "__main__":
     maybe_spawn_ranks()
 
-# bench.py reads the in-step kernel-class recorder and takes --opt A/B knobs: it binds the test / bench build of the library
-# (libfact_hip_dbg.so = the production objects + include/fact_hip_debug.h; mint_amd/_lib.py).  FACT_DEBUG_ABI=0 in the
-# environment runs the timed region on the production library instead (no `kernels` / `roofline` objects then).
-os.environ.setdefault("FACT_DEBUG_ABI", "1")
+# Which build of the library a bench process binds (mint_amd/_lib.py; ONE per process):
+#   --mode train (the driver's line): the PRODUCTION library libfact_hip.so runs the warm-up and the timed K steps; the
+#     `kernels` / `roofline` objects need the in-step kernel-class recorder of include/fact_hip_debug.h, so rank 0 then starts a
+#     CHILD of this script (--kernel-table-child) that binds libfact_hip_dbg.so - the same objects + the recorder - on the same
+#     GPU and reports the table of the same single-replica step;
+#   --opt KEY=INT (A/B knobs are debug options), --kernel-table-child, --mode ar / scaled (artefacts with a class table):
+#     the test / bench build for the whole process, and the line says so in `library`.
+# FACT_DEBUG_ABI in the environment overrides either way.
+def raw_flag(argv, name, default=None):
+    for i, a in enumerate(argv):
+        if a == name and i + 1 < len(argv):
+            return argv[i + 1]
+        if a.startswith(name + "="):
+            return a.split("=", 1)[1]
+    return default
+
+
+def wants_debug_build(argv):
+    return (any(a == "--opt" or a.startswith("--opt=") for a in argv) or "--kernel-table-child" in argv
+            or raw_flag(argv, "--mode", "train") != "train")
+
+
+if __name__ == "__main__":
+    os.environ.setdefault("FACT_DEBUG_ABI", "1" if wants_debug_build(sys.argv[1:]) else "0")
 
 # Data-parallel runs add a communication stream and RCCL's own to the engine's three: with HIP's default of 4
 # hardware queues some of them share a queue and serialise (one-GPU dry run with RCCL initialised, tools/attic/dp_probe.py:
@@ -138,6 +158,8 @@ def parse():
                          "Default 0: with the communication stream and RCCL's own the process then stays at <= 6 busy "
                          "hardware queues (GPU_MAX_HW_QUEUES = 7; an 8th busy queue doubled the step in the one-GPU dry "
                          "run, profiles/r02_dp_dry_run.txt) at ~0.2 ms per step")
+    ap.add_argument("--kernel-table-child", action="store_true",
+                    help="internal: warm up, record the in-step kernel-class table on libfact_hip_dbg.so, print it as JSON")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT",
                     help="engine test / bench knob for A/B runs (fact_debug_set_option), e.g. --opt wgrad_parts=1")
     return ap.parse_args()
@@ -205,14 +227,8 @@ def kernel_table(model, step_fn, nsteps):
                        frac=round(gbs / PEAK_HBM_GBS, 4), bytes_per_launch=r["bytes"] / r["launches"])
         rows.append(row)
     rows.sort(key=lambda x: -x["time_share"])
-    prof, src = rocprof_symbol_table()
-    for row in rows:  # both clocks side by side (see rocprof_symbol_table)
+    for row in rows:
         row["clock"] = "engine event recorder"
-        first = row["kernel"].split(" + ")[0]
-        hit = [v for k, v in prof.items() if k.startswith(first) or first.startswith(k)]  # (the summary truncates long symbols)
-        if len(hit) == 1:
-            row["rocprofv3_avg_us_same_symbol"] = hit[0]
-            row["rocprofv3_source"] = src
     return rows, tot / nsteps
 
 
@@ -565,8 +581,9 @@ def run_scaled(args, device, world=1, rank=0, dry=False):
         "step_tflops": round(step_flop / dt / 1e12, 1),
         "step_mfma_frac": round(step_flop / dt / 1e12 / (PEAK_BF16_TFLOPS * world), 4), "final_loss": round(loss, 5),
         "parity_vs_oracle": parity, "kernels": kern}
-    if comm is not None:
-        out_line["comm"] = comm
+    if world > 1:
+        import torch.distributed as dist
+        out_line["comm"] = dict(comm or {}, process_group=comm_backend_record(dist, dry))
     if dry:
         out_line["dry_run"] = "gloo, ranks sharing devices: control-flow check of the N > 1 path, not a measurement"
     print(json.dumps(out_line))
@@ -603,6 +620,60 @@ def scaled_parity(model, device):
             "gradient_tensors": len(grads), "worst_gradient_cosine": round(worst_cos, 5),
             "worst_gradient_cosine_tensor": worst_name, "worst_gradient_rel_frobenius": round(worst_rel, 4),
             "oracle": "fp32 PyTorch-CPU restatement (oracle/fact_oracle.py)", "seconds": round(time.perf_counter() - t0, 1)}
+
+
+def kernel_table_from_child(args, local_rank, B):
+    """The `kernels` table of a production-library run: a child of this script on the SAME GPU, bound to libfact_hip_dbg.so
+    (mint_amd/_lib.py binds one build per process), runs the same single-replica step - warm-up, a short timed region, then
+    --profile-steps recorded steps - and prints the rows.  Returns its JSON or None (the headline line never depends on it)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT",
+                        "TORCHELASTIC_RUN_ID", "FACT_DEBUG_ABI", "GPU_MAX_HW_QUEUES")}
+    env["FACT_DEBUG_ABI"] = "1"
+    vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+    env["HIP_VISIBLE_DEVICES"] = vis.split(",")[local_rank] if vis else str(local_rank)
+    env.pop("CUDA_VISIBLE_DEVICES", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--kernel-table-child", "--gpus", "1", "--steps", "5", "--warmup", "5",
+           "--batch", str(B), "--profile-steps", str(max(1, args.profile_steps)), "--side-stream", str(args.side_stream),
+           "--fuse-optimizer", str(args.fuse_optimizer), "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{") and "kernel_table_child" in line:
+                return json.loads(line)
+        print("kernel-table child failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-2000:]), file=sys.stderr)
+    except Exception as e:
+        print("kernel-table child failed: %r" % (e,), file=sys.stderr)
+    return None
+
+
+def reference_profile(kernel):
+    """rocprofv3's average for the dominant kernel's symbol from the newest COMMITTED `--kernel-trace --stats` summary of this
+    command (profiles/rNN_kernel_stats_bench_n1.txt) - an EARLIER run, kept apart from this run's own clocks (round-5
+    advisor: it read as a second clock of the same run)."""
+    prof, src = rocprof_symbol_table()
+    first = kernel.split(" + ")[0]
+    hit = [v for k, v in prof.items() if k.startswith(first) or first.startswith(k)]  # (the summary truncates long symbols)
+    if len(hit) != 1:
+        return None
+    return {"file": "profiles/" + src, "rocprofv3_avg_us_same_symbol": hit[0],
+            "note": "committed profile of an earlier run of the same command, NOT this run; compare with avg_launch_us "
+                    "only when the kernel has not changed since that file was committed"}
+
+
+def comm_backend_record(dist, dry):
+    """What the live process group is (round-5 review item 8): backend, world size and - for nccl = RCCL - the library version."""
+    rec = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+    try:
+        if rec["backend"] == "nccl":
+            v = torch.cuda.nccl.version()
+            rec["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:
+        rec["rccl_version"] = "unavailable: %r" % (e,)
+    if dry:
+        rec["note"] = "gloo dry run through the host"
+    return rec
 
 
 def main():
@@ -677,11 +748,32 @@ def main():
             file=sys.stderr)
 
     from mint_amd import _lib as L
-    if L.DEBUG_ABI or hasattr(L.lib(), "fact_kprof"):
+    has_recorder = L.DEBUG_ABI and hasattr(L.lib(), "fact_kprof")
+    if args.kernel_table_child:
+        # child of a production-library run: the table of the same single-replica step, on the test / bench build
+        assert has_recorder and world == 1, "--kernel-table-child binds libfact_hip_dbg.so at N = 1"
         rows, ksum_ms = kernel_table(model, lambda: trainer.train_step(it), max(1, args.profile_steps))
-    else:  # FACT_DEBUG_ABI=0: timed on the production library, which has no recorder
-        rows, ksum_ms = None, 0.0
+        child = {"kernel_table_child": True, "rows": rows, "ksum_ms": ksum_ms, "library": os.path.basename(L.LIB_PATH),
+                 "ms_per_step": round(dt / args.steps * 1e3, 3)}
+        if rows and rows[0]["name"] == "wgrad_group":
+            try:
+                child["standalone"] = wgrad_standalone(device)
+            except Exception as e:
+                child["standalone"] = {"error": repr(e)[:200]}
+        print(json.dumps(child))
+        return
     comm = comm_record(trainer, it, args, world)
+    rows, ksum_ms, standalone, table_from = None, 0.0, None, None
+    if has_recorder:  # --opt / FACT_DEBUG_ABI=1: the whole run is on the test / bench build
+        rows, ksum_ms = kernel_table(model, lambda: trainer.train_step(it), max(1, args.profile_steps))
+        table_from = "this process (%s)" % os.path.basename(L.LIB_PATH)
+    elif rank == 0 and args.profile_steps > 0:
+        torch.cuda.synchronize()
+        child = kernel_table_from_child(args, local_rank, B)
+        if child is not None:
+            rows, ksum_ms, standalone = child["rows"], child["ksum_ms"], child.get("standalone")
+            table_from = ("child process on the same GPU bound to %s (the production objects + the recorder of "
+                          "include/fact_hip_debug.h), single-replica step, %.3f ms/step there" % (child["library"], child["ms_per_step"]))
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         frames_per_s = world * B * 120 / (dt / args.steps)
@@ -704,43 +796,44 @@ def main():
             "step_mfma_frac": round(frames_per_s * FLOP_PER_FRAME * executed_flop_fraction() / 1e12
                                     / (PEAK_BF16_TFLOPS * world), 4),
             "final_loss": round(final_loss, 5),
-            "library": os.path.basename(L.LIB_PATH),
+            "library": os.path.basename(L.LIB_PATH),  # what ran the timed K steps
         }
-        if comm is not None:
-            out["comm"] = comm
+        if world > 1:  # the live process group rides in the comm record (backend, world, RCCL version)
+            out["comm"] = dict(comm or {}, process_group=comm_backend_record(dist, dry))
         if dry:
             out["dry_run"] = "gloo, ranks sharing devices: control-flow check of the N > 1 path, not a measurement"
-        if rows is None:  # production library: the headline numbers only
-            if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline()
-            print(json.dumps(out))
-    if rank == 0 and rows is not None:
-        out["kernels"] = rows
-        top = rows[0]
-        traffic, src = measured_traffic(top["name"])
-        out["roofline"] = {"bound": top["bound"], "kernel": top["kernel"], "class": top["name"],
-                           "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
-                           "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"],
-                           "time_share": top["time_share"],
-                           "flop_per_launch": top.get("flop_per_launch"), "cu_share": top.get("cu_share"),
-                           "frac_of_held_cus": top.get("frac_of_held_cus"), "traffic": traffic, "traffic_source": src,
-                           "clock": "engine event recorder (HIP events on the launch stream; ~2-3 us per launch above the "
-                                    "rocprofv3 kernel duration of the same dispatch, given beside it when the symbol is unique)",
-                           "rocprofv3_avg_us_same_symbol": top.get("rocprofv3_avg_us_same_symbol"),
-                           "how": "HIP events on the launch stream around every launch of the class, inside normal "
-                                  "train steps (all streams overlapping); sum of kernel-class time per step "
-                                  "%.2f ms vs %.2f ms wall" % (ksum_ms, ms_per_step)}
-        if top["name"] == "wgrad_group":
-            try:
-                out["roofline"]["standalone"] = wgrad_standalone(device)
-            except Exception as e:  # never lose the headline line to the extra measurement
-                out["roofline"]["standalone"] = {"error": repr(e)[:200]}
-        by = {r["name"]: r for r in rows}
-        if "attention_fwd" in by and "attention_bwd" in by:
-            out["attention"] = {
-                "fwd_tflops": by["attention_fwd"]["achieved"], "fwd_mfma_frac": by["attention_fwd"]["frac"],
-                "bwd_tflops": by["attention_bwd"]["achieved"], "bwd_mfma_frac": by["attention_bwd"]["frac"],
-                "note": "QK^T+PV algorithmic FLOPs / in-step launch time, all 16 layers; MFMA-busy PMC: profiles/"}
+        if rows:
+            out["kernels"] = rows
+            out["kernels_from"] = table_from
+            top = rows[0]
+            traffic, src = measured_traffic(top["name"])
+            out["roofline"] = {"bound": top["bound"], "kernel": top["kernel"], "class": top["name"],
+                               "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+                               "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"],
+                               "time_share": top["time_share"],
+                               "flop_per_launch": top.get("flop_per_launch"), "cu_share": top.get("cu_share"),
+                               "frac_of_held_cus": top.get("frac_of_held_cus"), "traffic": traffic, "traffic_source": src,
+                               "clock": "engine event recorder (HIP events on the launch stream around every launch of the "
+                                        "class, inside normal train steps, all streams overlapping; ~2-3 us per launch above "
+                                        "the rocprofv3 kernel duration of the same dispatch)",
+                               "how": "sum of kernel-class time per step %.2f ms vs %.2f ms wall; table from: %s" % (
+                                   ksum_ms, ms_per_step, table_from)}
+            ref = reference_profile(top["kernel"])
+            if ref:
+                out["roofline"]["reference_profile"] = ref
+            if standalone is None and has_recorder and top["name"] == "wgrad_group":
+                try:
+                    standalone = wgrad_standalone(device)
+                except Exception as e:  # never lose the headline line to the extra measurement
+                    standalone = {"error": repr(e)[:200]}
+            if standalone is not None:
+                out["roofline"]["standalone"] = standalone
+            by = {r["name"]: r for r in rows}
+            if "attention_fwd" in by and "attention_bwd" in by:
+                out["attention"] = {
+                    "fwd_tflops": by["attention_fwd"]["achieved"], "fwd_mfma_frac": by["attention_fwd"]["frac"],
+                    "bwd_tflops": by["attention_bwd"]["achieved"], "bwd_mfma_frac": by["attention_bwd"]["frac"],
+                    "note": "QK^T+PV algorithmic FLOPs / in-step launch time, all 16 layers; MFMA-busy PMC: profiles/"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -30,7 +30,7 @@ extern "C" {
  * fact_hip_debug.h (fact_set_option rejects them); fact_create zeroes a caller-provided gradient arena; fact_loss added;
  * option "adam_in_wgrad" added (when set, a fused step under "grad_overwrite" no longer writes the gradient-arena ranges
  * of the transformer-layer Dense kernels).  A host built against version 1 must be re-read against this header. */
-#define FACT_ABI_VERSION 2
+#define FACT_ABI_VERSION 3
 
 /* One transformer stack (mint/core/base_models.py:91-110) plus the modality it embeds. */
 typedef struct FactStackCfg {
@@ -121,6 +121,11 @@ int fact_forward_backward(FactHandle* h, const float* motion, const float* audio
  * counter and rewrites the bf16 weight shadows - one pass over p / m / v / g (36 bytes per parameter). */
 int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps, float clip_norm,
                    void* stream);
+/* tf.clip_by_global_norm (single_task_trainer.py:180-183) on the gradient arena IN PLACE, as its own step: under data
+ * parallelism every replica clips its OWN gradient before apply_gradients sums them (:180-187), i.e. before the
+ * all-reduce and therefore outside fact_adam_step.  grads *= clip_norm / max(||grads||_2, clip_norm); two kernels, no host
+ * synchronisation; `norm_out` (device float[1], may be NULL) receives the global norm.  (ABI 3) */
+int fact_clip_gradients(FactHandle* h, float clip_norm, float* norm_out, void* stream);
 /* Optimizer step inside the backward pass (no gradient clipping): call fact_adam_begin before
  * fact_forward_backward.  Without a gradient callback the engine updates the buckets itself on an internal
  * optimizer stream (Keras Adam + grad zeroing + bf16 shadows; joined before fact_forward_backward's work

@@ -64,6 +64,7 @@ SIGNATURES = {
     "fact_forward": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "fact_forward_backward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
     "fact_adam_step": (_i, [_vp, _f, _f, _f, _f, _f, _vp]),
+    "fact_clip_gradients": (_i, [_vp, _f, _vp, _vp]),
     "fact_adam_begin": (_i, [_vp, _f, _f, _f, _f]),
     "fact_adam_bucket": (_i, [_vp, _i, _vp]),
     "fact_adam_bucket_bf16": (_i, [_vp, _i, _vp, _vp]),

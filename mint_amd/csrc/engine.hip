@@ -254,6 +254,8 @@ struct FactHandle {
                       // wave), a small reduce on the wgrad stream replaces the column-sum pass over dh / x / dy.  Round 4:
                       // parity green, step unchanged (7.65 vs 7.66 ms: the dx kernel pays 22 -> 33 us on the dgrad chain for the
                       // 50 -> 3 x 15 us it takes off the wgrad stream) - off by default, DESIGN 6
+  int bias_in_wgrad = 1;  // round 6: dense_1 / dense_2 / to_out bias gradients as operand column sums inside the grouped wgrad launch
+                          // (TnProblem::csum) instead of a re-read of dpre / the residual gradients by col_tasks_kernel
   int wgrad_parts = 2;   // launches per layer of the grouped wgrad kernel (each ~190/parts workgroups wide)
   int wgrad_defer = 1;   // release a layer's wgrad batch behind the NEXT layer's GELU' dgrad (240 workgroups)
   int bwd_splitk = 0;    // in-kernel split-K for the N = 800 dgrad GEMMs: 1 = always, 2 = stacks of <= 4096 rows (encoders)
@@ -867,6 +869,11 @@ bool wgrad_group_ok(const FactHandle* h, const Stack& st, int M) {
   return h->wgrad_big && h->wgrad_tr && !(M & 31) && M >= 512 && !(st.d & 3) && !(st.ff & 3) && st.d >= 160;
 }
 
+// Do the grouped wgrad launches of this stack also produce the three Dense bias gradients (TnProblem::csum)?
+bool bias_in_wgrad_ok(const FactHandle* h, const Stack& st, int M) {
+  return h->bias_in_wgrad && wgrad_group_ok(h, st, M) && big_tn_group_has_colsum() && !(h->skip & 1);
+}
+
 // May this fact_forward_backward call run the optimizer inside the wgrad launches (FactHandle::adam_in_wgrad)?  Needs the
 // engine-owned fused step (fact_adam_begin, no gradient callback, no clipping), overwrite semantics for the layer
 // gradients, and EVERY layer of every stack on the grouped launch (16-wide units on both sides of each Dense kernel).
@@ -910,6 +917,11 @@ int wgrad_layer_group(FactHandle* h, const Stack& st, const LayerP& p, const Lay
   set(2, a.a, st.dp, d, xmid16, st.dp, d, G(h, p.wo.w), d, 0);          // dWo[d][d]   = attn^T dx_mid
   set(3, a.h1, st.dp, d, dqkv, st.qp, 3 * d, G(h, p.wqkv.w), 3 * d, 0); // dWqkv[d][3d] = LN1(x)^T dqkv
   g.overwrite = h->grad_overwrite;
+  if (bias_in_wgrad_ok(h, st, M)) {  // column sums of operands the launch streams anyway (atomics: the bias ranges are zeroed)
+    g.p[0].csum = G(h, p.b2);   // sum_rows dL/dx_out   (A operand of dW2)
+    g.p[1].csum = G(h, p.b1);   // sum_rows dpre        (B operand of dW1)
+    g.p[2].csum = G(h, p.bo);   // sum_rows dL/dx_mid   (B operand of dWo)
+  }
   if (h->wg_adam) {
     arm_adam(h, g, 0, p.w2); arm_adam(h, g, 1, p.w1); arm_adam(h, g, 2, p.wo); arm_adam(h, g, 3, p.wqkv);
   }
@@ -1004,9 +1016,10 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
     g.ep.out0 = a.x_out; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = a.x_mid; g.ep.ldr = d;
     with_ws(h, g, s);
     with_skinny_fwd(h, g, s);
-    // symmetric split-K finish (gemm.h GemmParams::sk_sym): the cross-modal stack's forward is the only work in flight on
-    // the device (the two encoder streams were joined before it, model_forward_hidden), so its 2 x 115 workgroups are
-    // co-resident; the encoder stacks run side by side and keep the exiting finish
+    // symmetric split-K finish (gemm.h GemmParams::sk_sym; OPT-IN since round 6 - debug option sk_sym = 1, gemm.hip g_sk_sym):
+    // within this handle the cross-modal stack's forward is the only work in flight (the two encoder streams were joined
+    // before it, model_forward_hidden), so its 2 x 115 workgroups are co-resident; what the engine cannot see - another
+    // handle, process or RCCL kernel on the same GPU - is why the spinning finish is not a default
     g.sk_sym = (&st == &h->cross) ? 1 : 0;
     if (l + 1 < st.L && st.la[l + 1].x_in == a.x_out) {  // LayerNorm 1 of the next layer of this stack
       LayerP& pn = st.lp[l + 1];
@@ -1117,6 +1130,9 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
         set(1, r.h2_c, dp, d, r.dpre_c, fp, ff, G(h, p.w1.w), ff, 0);
         set(2, r.a_c, dp, d, r.xmid16_c, dp, d, G(h, p.wo.w), d, 0);
         g.overwrite = h->grad_overwrite;
+        if (bias_in_wgrad_ok(h, st, M)) {
+          g.p[0].csum = G(h, p.b2); g.p[1].csum = G(h, p.b1); g.p[2].csum = G(h, p.bo);
+        }
         if (h->wg_adam) {
           arm_adam(h, g, 0, p.w2); arm_adam(h, g, 1, p.w1); arm_adam(h, g, 2, p.wo);
         }
@@ -1139,13 +1155,16 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
       KScope kpg(h, KP_PARAM_GRADS, w, 0, (double)Mr * (ff * 2.0 + d * 12.0) + (double)M * d * 6.0, 2);
       ColTasks ts;
       memset(&ts, 0, sizeof(ts));
-      ts.n = 3;
-      ts.M = Mr;  // compact rows: dense_1 bias, LayerNorm 2 (+ dense_2 bias), to_out bias
-      ts.t[0].dy = r.dpre_c; ts.t[0].ldy = fp; ts.t[0].dbias = G(h, p.b1); ts.t[0].C = ff;
-      ts.t[1].dh = r.dh2_c; ts.t[1].ld16 = dp; ts.t[1].x = r.x_mid_c; ts.t[1].mean = r.mean2_c; ts.t[1].rstd = r.rstd2_c;
-      ts.t[1].dy = r.dx16_c; ts.t[1].ldy = dp; ts.t[1].dgamma = G(h, p.ln2_g); ts.t[1].dbeta = G(h, p.ln2_b);
-      ts.t[1].dbias = G(h, p.b2); ts.t[1].C = d;
-      ts.t[2].dy = r.xmid16_c; ts.t[2].ldy = dp; ts.t[2].dbias = G(h, p.bo); ts.t[2].C = d;
+      ts.M = Mr;  // compact rows: LayerNorm 2 - and, unless the wgrad launch above took them (bias_in_wgrad), the three biases
+      ts.t[0].dh = r.dh2_c; ts.t[0].ld16 = dp; ts.t[0].x = r.x_mid_c; ts.t[0].mean = r.mean2_c; ts.t[0].rstd = r.rstd2_c;
+      ts.t[0].dgamma = G(h, p.ln2_g); ts.t[0].dbeta = G(h, p.ln2_b); ts.t[0].C = d;
+      ts.n = 1;
+      if (!(wgrad_group_ok(h, st, M) && bias_in_wgrad_ok(h, st, M))) {
+        ts.t[0].dy = r.dx16_c; ts.t[0].ldy = dp; ts.t[0].dbias = G(h, p.b2);
+        ts.t[1].dy = r.dpre_c; ts.t[1].ldy = fp; ts.t[1].dbias = G(h, p.b1); ts.t[1].C = ff;
+        ts.t[2].dy = r.xmid16_c; ts.t[2].ldy = dp; ts.t[2].dbias = G(h, p.bo); ts.t[2].C = d;
+        ts.n = 3;
+      }
       CHK(launch_col_tasks(ts, w));
       memset(&ts, 0, sizeof(ts));
       ts.n = 1;
@@ -1157,12 +1176,14 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
     if (two) sc.ev_batch[b.q] = stream_mark(h, w);
     return 0;
   }
+  bool bias_done = false;  // the three Dense bias gradients came out of the grouped wgrad launch (TnProblem::csum)
   {
     // (with the optimizer in the epilogue the class also moves 28 bytes per layer-kernel parameter: reported beside the FLOPs)
     KScope k(h, KP_WGRAD, w, 2.0 * (double)M * ((double)d * ff * 2 + (double)d * d * 4),
              h->wg_adam ? 28.0 * ((double)d * ff * 2 + (double)d * d * 4) : 0, h->wgrad_big ? h->wgrad_parts : 8);
     const int rc = (h->skip & 1) ? 0 : wgrad_layer_group(h, st, p, a, b.xin16, b.dpre, b.xmid16, b.dqkv, M, w);
     if (rc < 0) return rc;
+    bias_done = (rc == 0) && bias_in_wgrad_ok(h, st, M);
     if (rc > 0 && h->wg_adam) return fail(-1, "optimizer-in-wgrad step without the grouped wgrad launch");
     if (rc > 0) {
       CHK(wgrad_layer_tensor(h, a.g, fp, ff, b.xin16, dp, d, M, G(h, p.w2.w), d, w, b.slab));
@@ -1185,28 +1206,35 @@ int flush_batch(FactHandle* h, BwScratch& sc) {
     // what remains is the dense_1 bias (column sum of dpre) and two small reduces over those partial rows
     KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * ff * 2.0 + 2.0 * b.part_blocks * 3.0 * d * 4.0, 3);
     if (!(h->skip & 2)) {
-      CHK(launch_colsum_bf16(b.dpre, fp, G(h, p.b1), M, ff, ff, c));
-      CHK(launch_colreduce(b.part2, b.part_blocks, d, G(h, p.ln2_g), G(h, p.ln2_b), G(h, p.b2), c));
-      CHK(launch_colreduce(b.part1, b.part_blocks, d, G(h, p.ln1_g), G(h, p.ln1_b), G(h, p.bo), c));
+      if (!bias_done) CHK(launch_colsum_bf16(b.dpre, fp, G(h, p.b1), M, ff, ff, c));
+      CHK(launch_colreduce(b.part2, b.part_blocks, d, G(h, p.ln2_g), G(h, p.ln2_b), bias_done ? nullptr : G(h, p.b2), c));
+      CHK(launch_colreduce(b.part1, b.part_blocks, d, G(h, p.ln1_g), G(h, p.ln1_b), bias_done ? nullptr : G(h, p.bo), c));
     }
   } else if (h->ln_split) {
     // ONE launch: the dense_1 bias (column sum of dpre) and, per LayerNorm, gamma / beta from the dgrad output
     // plus the bias gradient of the GEMM that fed the residual add (dense_2 / to_out) = column sum of the
     // gradient that entered it, taken from its bf16 copy (xin16 / xmid16)
-    KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * (ff * 2.0 + d * 16.0), 1);
+    // bytes: the two LayerNorms read dh (bf16) + x (fp32) = 6 B per element; the bias sums - when the wgrad launch did not
+    // take them (bias_in_wgrad) - add dpre and the two residual gradients (bf16)
+    KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * (bias_done ? d * 12.0 : ff * 2.0 + d * 16.0), 1);
     ColTasks ts;
     memset(&ts, 0, sizeof(ts));
-    ts.n = 3;
     ts.M = M;
-    ts.t[0].dy = b.dpre; ts.t[0].ldy = fp; ts.t[0].dbias = G(h, p.b1); ts.t[0].C = ff;
-    ts.t[1].dh = b.dh2; ts.t[1].ld16 = dp; ts.t[1].x = a.x_mid; ts.t[1].mean = a.mean2; ts.t[1].rstd = a.rstd2;
-    ts.t[1].dy = b.xin16; ts.t[1].ldy = dp; ts.t[1].dgamma = G(h, p.ln2_g); ts.t[1].dbeta = G(h, p.ln2_b);
-    ts.t[1].dbias = G(h, p.b2); ts.t[1].C = d;
-    ts.t[2].dh = b.dh1; ts.t[2].ld16 = dp; ts.t[2].x = a.x_in; ts.t[2].mean = a.mean1; ts.t[2].rstd = a.rstd1;
-    ts.t[2].dy = b.xmid16; ts.t[2].ldy = dp; ts.t[2].dgamma = G(h, p.ln1_g); ts.t[2].dbeta = G(h, p.ln1_b);
-    ts.t[2].dbias = G(h, p.bo); ts.t[2].C = d;
+    ts.t[0].dh = b.dh2; ts.t[0].ld16 = dp; ts.t[0].x = a.x_mid; ts.t[0].mean = a.mean2; ts.t[0].rstd = a.rstd2;
+    ts.t[0].dgamma = G(h, p.ln2_g); ts.t[0].dbeta = G(h, p.ln2_b); ts.t[0].C = d;
+    ts.t[1].dh = b.dh1; ts.t[1].ld16 = dp; ts.t[1].x = a.x_in; ts.t[1].mean = a.mean1; ts.t[1].rstd = a.rstd1;
+    ts.t[1].dgamma = G(h, p.ln1_g); ts.t[1].dbeta = G(h, p.ln1_b); ts.t[1].C = d;
+    ts.n = 2;
+    if (!bias_done) {
+      // the bias gradient of the GEMM that fed each residual add (dense_2 / to_out) = column sum of the gradient that
+      // entered it, from its bf16 copy, and the dense_1 bias = column sum of dpre
+      ts.t[0].dy = b.xin16; ts.t[0].ldy = dp; ts.t[0].dbias = G(h, p.b2);
+      ts.t[1].dy = b.xmid16; ts.t[1].ldy = dp; ts.t[1].dbias = G(h, p.bo);
+      ts.t[2].dy = b.dpre; ts.t[2].ldy = fp; ts.t[2].dbias = G(h, p.b1); ts.t[2].C = ff;
+      ts.n = 3;
+    }
     if (!(h->skip & 2)) CHK(launch_col_tasks(ts, c));
-  } else {
+  } else if (!bias_done) {
     KScope kpg(h, KP_PARAM_GRADS, c, 0, (double)M * ff * 2.0, 1);
     CHK(launch_colsum_bf16(b.dpre, fp, G(h, p.b1), M, ff, ff, c));
   }
@@ -1850,6 +1878,10 @@ int fact_debug_set_option(FactHandle* h, const char* key, int value) {
     gemm_set_tn_cfg(value);
     return 0;
   }
+  if (!strcmp(key, "bias_in_wgrad")) {  // 0 = bias gradients by col_tasks_kernel (round-2..5 path), 1 = inside the grouped wgrad launch
+    h->bias_in_wgrad = value ? 1 : 0;
+    return 0;
+  }
   if (!strcmp(key, "wgrad_parts")) {
     h->wgrad_parts = value < 1 ? 1 : value;
     return 0;
@@ -2044,6 +2076,17 @@ int fact_adam_step(FactHandle* h, float lr, float beta1, float beta2, float eps,
   CHK(launch_adam(h->params, h->adam_m, h->adam_v, h->grads, h->arena_floats, (float)lr_t, beta1, beta2,
                   eps, gscale, s));
   return refresh_all(h, s);
+}
+
+int fact_clip_gradients(FactHandle* h, float clip_norm, float* norm_out, void* stream) {
+  if (!h) return fail(-1, "null handle");
+  if (!h->training) return fail(-1, "handle was created with training=0");
+  if (!(clip_norm > 0.f)) return fail(-1, "fact_clip_gradients: clip_norm must be positive");
+  hipStream_t s = (hipStream_t)stream;
+  // tf.clip_by_global_norm on this replica's own gradient (single_task_trainer.py:180-183), both halves on the device
+  HIPCHK(hipMemsetAsync(h->scalars + 9, 0, sizeof(float), s));
+  CHK(launch_sumsq(h->grads, h->arena_floats, h->scalars + 9, s));
+  return launch_clip_scale(h->grads, h->arena_floats, h->scalars + 9, clip_norm, norm_out, s);
 }
 
 int fact_adam_begin(FactHandle* h, float lr, float beta1, float beta2, float eps) {

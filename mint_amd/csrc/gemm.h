@@ -113,6 +113,14 @@ struct TnProblem {
   bf16_t* sd;    // bf16 shadow in out's orientation   [rows of out][ldsd]
   bf16_t* st;    // bf16 shadow, transposed            [cols of out][ldst]
   int ldsd, ldst;
+  // Column sums of an operand the launch holds anyway (round 6; staggered main loop only, big_tn_group_has_colsum()): the
+  // bias gradient of a Dense layer is the column sum over tokens of the gradient entering it, and that matrix IS an operand
+  // of one of the layer's weight gradients (dpre -> dense_1 bias, the bf16 residual gradients -> dense_2 / to_out bias).
+  //   trans_out = 0: csum[n] += sum_k B[k][n]  (n < N), by the workgroups of m-tile 0
+  //   trans_out = 1: csum[m] += sum_k A[k][m]  (m < M), by the workgroups of n-tile 0
+  // taken from the MFMA pipe (a constant ones fragment as the other operand: one extra 16-wide tile row per K step in one
+  // wave row / column of those workgroups), left with fp32 atomics.  nullptr = off.
+  float* csum;
 };
 struct TnGroup {
   TnProblem p[TN_GROUP_MAX];
@@ -126,6 +134,7 @@ struct TnGroup {
 // `parts` > 1 cuts the group's tiles into that many launches (same stream, in order) of about equal size: each
 // then occupies only ~tiles/parts CUs, which leaves room for the CU-exclusive kernels of another stream.
 int launch_big_tn_group(TnGroup g, hipStream_t stream, int parts = 1);
+bool big_tn_group_has_colsum();  // does the selected main loop (gemm_set_tn_cfg) honour TnProblem::csum?
 void gemm_set_tn_cfg(int v);  // 0 = 160x256 tiles (default), 1 = 160x384 tiles
 
 // skinny-M epilogue pass (gemm_big.hip): out = epilogue(acc[M][ldacc]), acc <- 0
@@ -141,6 +150,6 @@ void gemm_set_tile192(int v);     // auto mode: 1 = 192x160 tiles for the whole-
 void gemm_set_k64(int v);         // auto mode: 1 = 256x160 GEMMs run on 64-deep ring slots (BIG_256x160_K64)
 void gemm_set_big_impl(int v);    // auto mode: 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel
 void gemm_set_tile128x160(int v);  // auto mode: 1 (default) = 128x160 tiles (two workgroups per CU) for the short-K N = 800 GEMMs, 0 = 256x128
-void gemm_set_sk_sym(int v);      // 0 = never the symmetric 2-way split-K finish (GemmParams::sk_sym), 1 = when asked for (default)
+void gemm_set_sk_sym(int v);      // 1 = allow the symmetric 2-way split-K finish where a caller asks for it (GemmParams::sk_sym); 0 (default) = never
 void gemm_set_splitk_max(int v);  // in-kernel split-K of the 256x160 tile: max slices (default 4, 1 = off)
 void gemm_set_nt_band(int band);   // NT tile band height (1 = row-major)

@@ -893,7 +893,10 @@ int band_for(int tiles, int tm, int bm, int bn) {
   return band;
 }
 
-int g_sk_sym = 1;  // A/B knob (gemm_set_sk_sym): 0 = never the symmetric 2-way split-K finish
+int g_sk_sym = 0;  // OPT-IN (debug option sk_sym / gemm_set_sk_sym(1)): the symmetric 2-way split-K finish spins on its peer slice, which
+                   // is only safe while nothing else can keep one of the launch's workgroups off the chip (a second handle, another
+                   // process, a CU mask, RCCL kernels - none of which the engine can see); round 5 measured it at 0.02 ms per step,
+                   // inside the box spread (profiles/r05_ab_symmetric_splitk.txt).  Round 6: off unless asked for.
 // short-K N = 800 GEMMs (out-projection forward / dgrad) on 128x160 instead of 256x128 tiles, two workgroups per CU either way:
 // 45 x 5 = 225 workgroups instead of 23 x 7 = 161 (with 12.5 % column padding) at M = 5760, so the epilogue streams from 225
 // CUs.  Round 5: stand-alone 21.2 -> 18.8 us (+ residual), 14.3 -> 13.1 us (bf16); in the step 26.0 -> 25.0 and 28.2 -> 25.6 us
@@ -955,9 +958,9 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
     if (variant == 19) cfg = k64_ok ? BIG_256x256_K64 : BIG_256x256;
     if (variant == 20) cfg = BIG_192x160_K64;
     if (variant == 21) cfg = BIG_128x160;
-    if (variant == 0 && g_tile128x160 && cfg == BIG_256x128 && p.N % 160 == 0 && p.N <= 960 &&
+    if (variant == 0 && g_tile128x160 && cfg == BIG_256x128 && p.N % 160 == 0 && p.N <= 960 && p.K < 1536 &&
         (EPI == EPI_F32_BIAS_RESID || EPI == EPI_HEADS || EPI == EPI_BF16))
-      cfg = BIG_128x160;  // A/B knob: the short-K N = 800 GEMMs on 128x160 tiles
+      cfg = BIG_128x160;  // the SHORT-K N = 800 GEMMs on 128x160 tiles (long K: the tile loses, profiles/r05_tile128x160_long_k.txt)
     if (g_k64 && variant == 0 && k64_ok) {
       if (cfg == BIG_256x160 && EPI == EPI_BF16 && g_tile192 && !ws && p.M % 192 == 0 && (p.M / 192) * ((p.N + 159) / 160) <= 256)
         cfg = BIG_192x160_K64;  // the whole-K dgrads of the backward chain: more, smaller tiles in the one round they get

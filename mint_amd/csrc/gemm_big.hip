@@ -228,10 +228,14 @@ constexpr int DMA_FIRST = BIG_DMA_FIRST;
 #define BIG_DMA_IN_MFMA 0  // A/B build knob: this many of a wave's LDS-DMA pieces per stage are issued from inside
 #endif                     // its multiply phase (spread between the MFMAs) instead of its read phase
 
-template <class C, bool TN, bool SWAP>
+// CS (TN only): the waves with `do_cs` also accumulate cs[x] += X_x * ones per K step - the column sums over k of the operand
+// on the MFMA-A side (SWAP: the B units bfr[j], else the A units af[i]); row r of cs[x] in every lane column is
+// sum_k operand[k][unit x, column (lane >> 4) * 4 + r].  The multiply phase of this loop has slack under the other group's
+// read phase (TN: transpose reads, ~2x the multiply phase), which is where the extra MFMAs go.
+template <class C, bool TN, bool SWAP, bool CS = false>
 DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1], const unsigned (&sadv)[C::LPS_LO + 1],
                          const unsigned (&voff)[C::LPS_LO + 1], const int (&dst)[C::LPS_LO + 1], int nk, int wave,
-                         int wm, int wn, int lane, f32x4 (&acc)[C::MR][C::NR]) {
+                         int wm, int wn, int lane, f32x4 (&acc)[C::MR][C::NR], bool do_cs = false, f32x4* cs = nullptr) {
   constexpr int MR = C::MR, NR = C::NR, NST = C::NSTAGE, DIST = C::DIST, STAGE = C::STAGE_BYTES;
   constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
   const int grp = wave >> 2;  // stagger group: waves 0-3 lead, waves 4-7 run one phase behind
@@ -376,6 +380,13 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
             }
         }
       }
+    if constexpr (CS) {
+      if (do_cs) {  // wave-uniform
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+#pragma unroll
+        for (int x = 0; x < (SWAP ? NR : MR); ++x) cs[x] = mfma16(SWAP ? bfr[x] : af[x], ones, cs[x]);
+      }
+    }
     if constexpr (BIG_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);
     if (grp == 0) wait_ahead();
     __builtin_amdgcn_s_barrier();
@@ -716,6 +727,18 @@ constexpr bool kStagedF32 = (EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_RESID);
 template <int EPI>
 DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f32x4 v);
 
+// accumulator rows (16-row MFMA tiles) per pass of the staged fp32 epilogue: the largest divisor of MR whose 8 wave regions fit
+// the idle ring (shared by the epilogue and the symmetric split-K finish, which hands each slice whole passes)
+template <class C>
+constexpr int f32_pass_rows() {
+  constexpr int MR = C::MR, STR = C::NR * 64 + 16;
+  return (C::NW * MR * 16 * STR <= C::LDS_BYTES)                          ? MR
+         : (MR % 2 == 0 && C::NW * (MR / 2) * 16 * STR <= C::LDS_BYTES)  ? MR / 2
+         : (MR % 3 == 0 && C::NW * (MR / 3) * 16 * STR <= C::LDS_BYTES)  ? MR / 3
+         : (MR % 4 == 0 && C::NW * (MR / 4) * 16 * STR <= C::LDS_BYTES)  ? MR / 4
+                                                                        : 1;
+}
+
 template <class C, int EPI>
 __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(const GemmParams p) {
   constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
@@ -726,7 +749,8 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
 
   const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM - 1) / BM;
   int m0, n0;
-  // split-K: the slices of a tile are neighbouring logical ids (same XCD, dispatched together)
+  // split-K: the slices of a tile are neighbouring logical ids (usually the same XCD - not when an XCD's share of the grid is
+  // odd, e.g. ids 28 / 29 of 230 - which only matters for speed: the finish is placement-independent)
   const int lid = xcd_logical_id();
   const int z = lid % p.splitk, tile = lid / p.splitk;
   {
@@ -795,8 +819,10 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     constexpr unsigned WG_BYTES = (unsigned)BM * BN * 4;
     char* tile_slabs = reinterpret_cast<char*>(p.sk_slab) + (size_t)tile * p.splitk * WG_BYTES;
     const unsigned lane_off = (unsigned)(wave * MR * NR * 1024 + lane * 16);
-    constexpr bool SYM_OK = kStagedF32<EPI> && (MR % 2 == 0) &&
-                            (C::NW * (MR / 2) * 16 * (NR * 64 + 16) <= C::LDS_BYTES);  // epilogue passes of <= MR / 2 rows
+    // epilogue passes of <= MR / 2 rows that never straddle the halves: the staged fp32 epilogue below runs CH = kF32PassRows
+    // accumulator rows per pass, and a slice must own whole passes
+    constexpr int CHF = f32_pass_rows<C>();
+    constexpr bool SYM_OK = kStagedF32<EPI> && (MR % 2 == 0) && CHF <= MR / 2 && (MR / 2) % CHF == 0;
     const bool sym = SYM_OK && p.sk_sym && p.splitk == 2;
     {
       const __amdgpu_buffer_rsrc_t mine =
@@ -971,11 +997,7 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
   }
   if constexpr (kStagedF32<EPI>) {
     constexpr int ROWB = NR * 64, STR = ROWB + 16, CPR = ROWB / 16;
-    constexpr int CH = (C::NW * MR * 16 * STR <= C::LDS_BYTES)                          ? MR
-                       : (MR % 2 == 0 && C::NW * (MR / 2) * 16 * STR <= C::LDS_BYTES)  ? MR / 2
-                       : (MR % 3 == 0 && C::NW * (MR / 3) * 16 * STR <= C::LDS_BYTES)  ? MR / 3
-                       : (MR % 4 == 0 && C::NW * (MR / 4) * 16 * STR <= C::LDS_BYTES)  ? MR / 4
-                                                                                   : 1;
+    constexpr int CH = f32_pass_rows<C>();
     constexpr int REG = CH * 16 * STR;
     constexpr int TOT = CH * 16 * CPR, IT = (TOT + 63) / 64;
     const bool aligned = !(p.N & 3) && !(ep.ldo0 & 3) && (EPI != EPI_F32_BIAS_RESID || !(ep.ldr & 3));
@@ -1251,9 +1273,24 @@ __global__ __launch_bounds__(C::NW * 64, 1) void big_tn_kernel(const TnGroup g) 
   for (int i = 0; i < MR; ++i) mrow[i] = m0 + TnImg<BM>::template unit_of<C::WGM, MR>(wm, i) * 16;
 #pragma unroll
   for (int j = 0; j < NR; ++j) ncol[j] = n0 + TnImg<BN>::template unit_of<C::WGN, NR>(wn, j) * 16;
+  // column sums of an operand (TnProblem::csum): the staggered loop only
+  constexpr int CSN = MR > NR ? MR : NR;
+  f32x4 cs[CSN];
+#pragma unroll
+  for (int x = 0; x < CSN; ++x) cs[x] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (!pr.trans_out) {
+    const bool do_cs = (PF == 0) && pr.csum != nullptr && tmi == 0 && wm == 0;
     if constexpr (PF) tn_mainloop_pf<C, true, PF >= 2, (PF > 2 ? PF - 2 : 0)>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
-    else big_mainloop<C, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+    else big_mainloop<C, true, true, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc, do_cs, cs);
+    if (do_cs && (lane & 15) == 0) {  // cs[j][r] = sum_k B[k][ncol[j] + (lane >> 4) * 4 + r], replicated over lane & 15
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = ncol[j] + (lane >> 4) * 4 + r;
+          if (n < pr.N) atomicAdd(pr.csum + n, cs[j][r]);
+        }
+    }
     if constexpr (ADAM) {
       tn_adam_epilogue<C, false>(smem, pr, g.lr_t, g.b1, g.b2, g.eps, acc, mrow, ncol, m0, n0, wave, wm, wn, lane);
       return;
@@ -1284,8 +1321,18 @@ __global__ __launch_bounds__(C::NW * 64, 1) void big_tn_kernel(const TnGroup g) 
       }
     }
   } else {
+    const bool do_cs = (PF == 0) && pr.csum != nullptr && tni == 0 && wn == 0;
     if constexpr (PF) tn_mainloop_pf<C, false, PF >= 2, (PF > 2 ? PF - 2 : 0)>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
-    else big_mainloop<C, true, false>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+    else big_mainloop<C, true, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc, do_cs, cs);
+    if (do_cs && (lane & 15) == 0) {  // cs[i][r] = sum_k A[k][mrow[i] + (lane >> 4) * 4 + r]
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mrow[i] + (lane >> 4) * 4 + r;
+          if (m < pr.M) atomicAdd(pr.csum + m, cs[i][r]);
+        }
+    }
     if constexpr (ADAM) {
       tn_adam_epilogue<C, true>(smem, pr, g.lr_t, g.b1, g.b2, g.eps, acc, mrow, ncol, m0, n0, wave, wm, wn, lane);
       return;
@@ -1572,6 +1619,7 @@ int launch_big_tn_group_t(TnGroup g, hipStream_t s, int parts) {
 }
 
 void gemm_set_tn_cfg(int v) { g_tn_cfg = v; }
+bool big_tn_group_has_colsum() { return g_tn_cfg == 0; }
 
 int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
   if (g_tn_cfg == 1) return launch_big_tn_group_t<Cfg160x256, 1>(g, s, parts);

@@ -146,3 +146,5 @@ int launch_scatter_rows_zero(const float* dxc, int B, int n, int T, int C, float
 int launch_slab_reduce(const float* slabs, size_t stride, int nslab, float* out, size_t n, hipStream_t s);
 // sum of squares of a flat f32 buffer -> out[0] (atomicAdd), and flat scale
 int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s);
+// g *= clip / max(sqrt(*sumsq), clip), *sumsq read on the device; norm_out (may be null) <- sqrt(*sumsq)
+int launch_clip_scale(float* g, size_t n, const float* sumsq, float clip, float* norm_out, hipStream_t s);

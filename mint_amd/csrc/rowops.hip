@@ -1031,6 +1031,22 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float4* __restrict__ g
   if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
 }
 
+// tf.clip_by_global_norm, second half: g *= clip / max(sqrt(sumsq), clip) with the sum of squares read ON THE DEVICE (no host
+// round trip between the two kernels); norm_out (optional) receives the global norm
+__global__ __launch_bounds__(256) void clip_scale_kernel(float4* __restrict__ g, size_t n4, const float* __restrict__ sumsq,
+                                                         float clip, float* __restrict__ norm_out) {
+  const float norm = sqrtf(*sumsq);
+  const float sc = clip / fmaxf(norm, clip);
+  if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = norm;
+  if (sc == 1.0f) return;  // uniform: nothing to clip
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = g[i];
+    v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+    g[i] = v;
+  }
+}
+
 // out[i] += sum_z slabs[z*stride + i]  (split-K partial sums of a wgrad GEMM)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, size_t stride,
                                                           int nslab, float* __restrict__ out, size_t n4) {
@@ -1348,5 +1364,11 @@ int launch_sumsq(const float* g, size_t n, float* out, hipStream_t s) {
   if (n & 3) return -1;
   FACT_LAUNCH(sumsq_kernel, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, s,
                      (const float4*)g, n >> 2, out);
+  return 0;
+}
+
+int launch_clip_scale(float* g, size_t n, const float* sumsq, float clip, float* norm_out, hipStream_t s) {
+  if (n & 3) return -1;
+  FACT_LAUNCH(clip_scale_kernel, dim3(grid_for(n >> 2, 256, 2048)), dim3(256), 0, s, (float4*)g, n >> 2, sumsq, clip, norm_out);
   return 0;
 }

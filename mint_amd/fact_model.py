@@ -297,6 +297,13 @@ class FACTModel:
             L.check(L.lib().fact_adam_bucket_bf16(self._h, int(bucket), L.ptr(grads_bf16),
                                                   C.c_void_p(stream.cuda_stream)))
 
+    def clip_gradients(self, clip_norm):
+        """tf.clip_by_global_norm on this replica's OWN gradient arena, in place (single_task_trainer.py:180-183): the
+        data-parallel step clips before the gradients are summed (:180-187), i.e. outside apply_adam.  Engine kernels
+        (fact_clip_gradients), no host synchronisation."""
+        self._require_built()
+        L.check(L.lib().fact_clip_gradients(self._h, float(clip_norm), None, L.cur_stream()))
+
     def apply_adam(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clip_norm=0.0):
         L.check(L.lib().fact_adam_step(self._h, float(lr), float(beta_1), float(beta_2), float(epsilon),
                                        float(clip_norm), L.cur_stream()))

@@ -81,14 +81,6 @@ def allreduce_gradients(grad_arena, bucket_bytes=64 << 20, async_op=False):
     return works
 
 
-def clip_local_gradients(grad_arena, clip_norm):
-    """tf.clip_by_global_norm on this replica's flat gradient arena (alignment padding is zero), in place,
-    no host sync.  Only used when clipping is requested under data parallelism (not the shipped config)."""
-    norm = torch.linalg.vector_norm(grad_arena)
-    grad_arena.mul_(clip_norm / torch.clamp(norm, min=clip_norm))
-    return norm
-
-
 class OverlappedGradReducer:
     """Sum-all-reduces gradient buckets on a dedicated communication stream WHILE the backward pass is still
     running: the engine reports each contiguous bucket as soon as its producers are enqueued (head, cross
@@ -325,7 +317,8 @@ class SingleTaskTrainer:
         if R > 1 and self.grad_clip_norm > 0.:
             # tf.clip_by_global_norm runs on each replica's OWN gradient before apply_gradients sums
             # them (:180-187): scale the local arena first, then reduce; nothing is left for Adam to clip
-            clip_local_gradients(self.model.grad_arena, self.grad_clip_norm)
+            # (engine kernels: fact_clip_gradients - sum of squares + in-place scale on the device, no host sync)
+            self.model.clip_gradients(self.grad_clip_norm)
             clip_in_adam = 0.0
         if self._reducer is not None:
             self._reducer.finish()

@@ -23,6 +23,10 @@ class OracleModel:
         self.grad_arena += torch.cat([grads[n].flatten() for n in self.names])
         return loss
 
+    def clip_gradients(self, clip_norm):
+        norm = torch.linalg.vector_norm(self.grad_arena)
+        self.grad_arena.mul_(clip_norm / torch.clamp(norm, min=clip_norm))
+
     def apply_adam(self, lr, beta_1=0.9, beta_2=0.999, epsilon=1e-7, clip_norm=0.0):
         grads, off = {}, 0
         for n, s in zip(self.names, self.sizes):

@@ -56,7 +56,7 @@ def test_production_library_exports_exactly_the_public_header(lib):
     assert _exported(L.PROD_LIB_PATH) == public
     assert _exported(L.DEBUG_LIB_PATH) == sorted(public + debug)
     prod = C.CDLL(L.PROD_LIB_PATH)
-    assert prod.fact_abi_version() == 2
+    assert prod.fact_abi_version() == 3
     for n in debug:
         assert not hasattr(prod, n), n
     assert L.DEBUG_ABI and L.LIB_PATH == L.DEBUG_LIB_PATH  # tests/conftest.py selected the test / bench build
@@ -75,7 +75,7 @@ def test_public_header_carries_no_lab_bench():
 
 
 def test_abi_version_and_struct_layout(lib):
-    assert lib.fact_abi_version() == 2
+    assert lib.fact_abi_version() == 3
     assert C.sizeof(L.FactStackCfg) == 24 and C.sizeof(L.FactConfig) == 3 * 24 + 8
     assert C.sizeof(L.FactParamDesc) == 96 + 8 + 12 + 4  # name, offset, rows/cols/kind, padding
     assert C.sizeof(L.FactArenas) == 32

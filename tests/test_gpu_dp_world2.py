@@ -27,15 +27,22 @@ def _rdzv():
     return path
 
 
-def _worker(rank, world, path, q, bf16, fused, clip=0.0, steps=STEPS):
+def _worker(rank, world, path, q, bf16, fused, clip=0.0, steps=STEPS, backend="gloo"):
     try:
         import torch.distributed as dist
         from mint_amd import model_builder
         from mint_amd.trainer import Adam, SingleTaskTrainer
         from tests.test_gpu_model import make_config
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-        torch.cuda.set_device(0)
-        dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
+        if backend == "nccl":  # RCCL over xGMI: one rank per GPU (needs >= world GPUs; the driver's multi-GPU boxes)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(rank)
+            dist.init_process_group("nccl", init_method="file://" + path, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", rank))
+            assert dist.get_backend() == "nccl"
+        else:
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=world)
         cfg = O.TINY_CFG
         full = O.synthetic_batch(cfg, PER_RANK * world, T, seed=5)
         mine = {k: v[PER_RANK * rank:PER_RANK * (rank + 1)].float().cuda() for k, v in full.items()}
@@ -71,11 +78,11 @@ def _worker(rank, world, path, q, bf16, fused, clip=0.0, steps=STEPS):
         raise
 
 
-def _run_world2(bf16, fused, clip=0.0, steps=STEPS):
+def _run_world2(bf16, fused, clip=0.0, steps=STEPS, backend="gloo"):
     path = _rdzv()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, path, q, bf16, fused, clip, steps)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, path, q, bf16, fused, clip, steps, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = {}
@@ -118,7 +125,22 @@ def _single_process_global_batch():
 @pytest.mark.parametrize("bf16,fused", [(False, True), (False, False), (True, True), (True, False)],
                          ids=["fp32-adam_per_bucket", "fp32-adam_after", "bf16-adam_per_bucket", "bf16-adam_after"])
 def test_engine_two_replicas_one_gpu(bf16, fused):
-    res = _run_world2(bf16, fused)
+    _check_two_replicas(bf16, fused, "gloo")
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the real RCCL path needs two GPUs (one rank per device)")
+@pytest.mark.parametrize("bf16,fused", [(False, True), (True, True), (True, False)],
+                         ids=["fp32-adam_per_bucket", "bf16-adam_per_bucket", "bf16-adam_after"])
+def test_engine_two_replicas_two_gpus_rccl(bf16, fused):
+    """The same assertions through the REAL backend (`nccl` = RCCL over xGMI, one rank per GPU): bucket all-reduces on the
+    communication stream overlapped with backward, Adam of a bucket behind its collective.  Skipped on one-GPU boxes;
+    the first multi-GPU box that runs the GPU suite exercises RCCL here and not only in the scaling bench (round-5 review
+    item 8; reference trainer.py:125-135, single_task_trainer.py:158,186-187)."""
+    _check_two_replicas(bf16, fused, "nccl")
+
+
+def _check_two_replicas(bf16, fused, backend):
+    res = _run_world2(bf16, fused, backend=backend)
     # identical replicas: same reduced gradients, same deterministic optimizer
     assert np.array_equal(res[0][0], res[1][0]), "replicas diverged"
     assert np.array_equal(res[0][3], res[1][3]), "replica optimizer state diverged"

@@ -268,6 +268,16 @@ def test_fact_v5_headline_batch_all_gradients_vs_oracle():
     print("fact_v5 B=16: worst gradient cosine %.5f (%s)" % worst)
 
 
+def test_fact_v5_trainer_steps_vs_oracle():
+    """The path bench.py times at the configuration it times (fact_v5, batch 16, SingleTaskTrainer defaults: optimizer inside
+    backward, grad_overwrite, supervised-rows shortcut), three optimizer steps against the fp32 oracle's train_step:
+    per-step loss, first / second moments and the parameter update of all 184 tensors (tests/_trainer_parity.py holds the
+    bounds; tests/test_gpu_production_lib.py runs the same on libfact_hip.so)."""
+    from tests import _trainer_parity
+    r = _trainer_parity.run()
+    assert r["library"].startswith("libfact_hip")
+
+
 def test_tiny_adam_state_per_tensor_after_three_steps():
     """Three optimizer steps on the engine vs the oracle (Keras Adam, epsilon outside the bias correction), compared
     PER TENSOR: parameters, first and second moments.  Tolerances (bf16 gradients into fp32 Adam): m rel-Frobenius
@@ -916,6 +926,27 @@ def test_clip_by_global_norm_in_adam_step_vs_oracle():
     # the test has teeth: the un-clipped first moment is ~4x the clipped one
     some = "cross_modal_layer/output/kernel"
     assert float(m_noclip[some].norm()) > 2.0 * float(pm[some].norm())
+
+
+def test_clip_gradients_entry_point_matches_torch():
+    """fact_clip_gradients (round 6: the per-replica clip of the data-parallel step, single_task_trainer.py:180-187, on engine
+    kernels instead of ATen): g * clip / max(||g||, clip) on the whole arena, with an active and an inactive clip norm."""
+    cfg = O.TINY_CFG
+    model = model_builder.build(make_config(cfg), True)
+    gb = gpu_batch(O.synthetic_batch(cfg, 4, 8, seed=5))
+    model.build(4, 225, 35)
+    _randomize(model, seed=3)
+    model.grad_arena.zero_()
+    model.forward_backward(gb, gb["target"])
+    g = model.grad_arena.detach().clone()
+    gn = float(g.double().norm())
+    for clip in (0.3 * gn, 4.0 * gn):
+        model.grad_arena.copy_(g)
+        model.clip_gradients(clip)
+        torch.cuda.synchronize()
+        want = g.double() * (clip / max(gn, clip))
+        assert rel(model.grad_arena, want) < 1e-6, (clip, gn)
+    model.grad_arena.zero_()
 
 
 def test_options_survive_a_recreated_handle(continuous_attention):

@@ -201,7 +201,7 @@ def test_gemm_nt_splitk_symmetric_finish(M, N, K):
                 o = torch.full((M, N), float("nan"), device=DEV)
                 _gemm_nt(L.EPI_F32_BIAS_RESID, A, B, M, N, K, o, bias=bias, resid=resid)
             finally:
-                lib.fact_debug_gemm_sk_sym(1)
+                lib.fact_debug_gemm_sk_sym(0)  # the library default since round 6: opt-in only
             outs.append(o)
         assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "it %d: symmetric vs exiting finish" % it
         _close(outs[0], A.float() @ B.float().t() + bias + resid, 1e-4, 2e-3, "symmetric finish it%d" % it)

@@ -41,3 +41,16 @@ def test_production_library_runs_smoke_and_refuses_debug_entry_points():
     out = subprocess.run([sys.executable, "-c", SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "smoke ok" in out.stdout and "production library ok" in out.stdout
+
+
+def test_production_library_trainer_steps_vs_oracle_at_the_benchmark_config():
+    """Round-5 review item 3: the benchmark path (fact_v5, batch 16, SingleTaskTrainer defaults, three optimizer steps)
+    against the oracle ON THE PRODUCTION LIBRARY - the same bounds tests/test_gpu_model.py::
+    test_fact_v5_trainer_steps_vs_oracle enforces on the test / bench build (tests/_trainer_parity.py)."""
+    env = dict(os.environ)
+    env.pop("FACT_DEBUG_ABI", None)
+    env.pop("FACT_LIB", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_trainer_parity.py")], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "trainer parity ok on libfact_hip.so" in out.stdout, out.stdout[-2000:]
