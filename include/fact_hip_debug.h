@@ -41,6 +41,8 @@ int fact_kprof_kernels(FactHandle* h, int cls, char* buf, int cap);
  *   "wgrad_tr"       1 = wgrad GEMM builds its fragments with the LDS transpose read, 0 = explicit transposes
  *   "wgrad_slab"     1 = split-K partials as plain stores + a streaming reduce, 0 = fp32 atomics
  *   "fuse_adam_cast" 1 = Adam writes the bf16 weight shadows itself, 0 = Adam, then a cast/transpose pass
+ *   "bias_in_wgrad"  1 (default) = the dense_1 / dense_2 / to_out bias gradients are operand column sums inside the grouped
+ *                    wgrad launch (gemm.h TnProblem::csum), 0 = col_tasks_kernel re-reads dpre and the residual gradients
  *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "ln_cs", "bwd_splitk", "adam_hold", "ln_fuse", "lite_stream", "keep_pre":
  *                    scheduling / fusion switches of the A/B runs documented in DESIGN.md sections 3 and 6
  *   "tn_loop", "attn_variant", "adam_variant", "big_impl", "tile192", "tile128x160", "sk_sym", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on
@@ -63,6 +65,13 @@ int fact_op_gemm_tn(const void* A, int lda, const void* B, int ldb, int Mo, int 
 int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                           float* const* out, const int* ldo, const int* Mo, const int* No, const int* trans, int K,
                           void* stream);
+/* The same launch that also leaves operand column sums (gemm.h TnProblem::csum; engine option "bias_in_wgrad"): csum[i] != NULL
+ * adds sum_k B_i[k][n] (n < No_i) when trans[i] = 0, sum_k A_i[k][m] (m < Mo_i) when trans[i] = 1, with fp32 atomics - the
+ * bias gradient of the Dense layer whose incoming gradient is that operand (single_task_trainer.py:175-178 through
+ * base_models.py:51-53,69).  Staggered main loop only (fact_debug_gemm_tn_cfg low byte 0). */
+int fact_op_gemm_tn_group_cs(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                             float* const* out, const int* ldo, const int* Mo, const int* No, const int* trans,
+                             float* const* csum, int K, void* stream);
 /* The same launch with the optimizer in its epilogue (engine option "adam_in_wgrad", gemm.h TnGroup::adam): problem i
  * updates p_i / m_i / v_i (fp32, indexed like out_i would be: [Mo_i][No_i], or [No_i][Mo_i] when trans[i]) with Keras Adam
  * on the gradient A_i^T B_i and writes the bf16 shadows s_i (same orientation, row pitch lds_i) and t_i (transposed, row

@@ -89,6 +89,8 @@ SIGNATURES = {
     "fact_op_gemm_tn": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "fact_op_gemm_tn_group": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp),
                                    C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _vp]),
+    "fact_op_gemm_tn_group_cs": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp),
+                                      C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_vp), _i, _vp]),
     "fact_op_gemm_tn_group_adam": (_i, [_i, C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp),
                                         C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_i), C.POINTER(_vp),
                                         C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), C.POINTER(_i), _i, _f, _f, _f, _f, _vp]),

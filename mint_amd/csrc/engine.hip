@@ -2386,6 +2386,23 @@ int fact_op_gemm_tn_group(int n, const void* const* A, const int* lda, const voi
   CHK(launch_big_tn_group(g, (hipStream_t)stream, g_op_tn_parts));
   return 0;
 }
+int fact_op_gemm_tn_group_cs(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
+                             float* const* out, const int* ldo, const int* Mo, const int* No, const int* trans,
+                             float* const* csum, int K, void* stream) {
+  if (n < 1 || n > TN_GROUP_MAX) return fail(-1, "1..4 problems");
+  if (!big_tn_group_has_colsum()) return fail(-1, "the selected wgrad main loop has no operand column sums (tn_loop = 0 only)");
+  TnGroup g;
+  memset(&g, 0, sizeof(g));
+  g.n = n;
+  g.K = K;
+  for (int i = 0; i < n; ++i) {
+    TnProblem& q = g.p[i];
+    q.A = (const bf16_t*)A[i]; q.lda = lda[i]; q.B = (const bf16_t*)B[i]; q.ldb = ldb[i];
+    q.out = out[i]; q.ldo = ldo[i]; q.M = Mo[i]; q.N = No[i]; q.trans_out = trans[i]; q.csum = csum[i];
+  }
+  CHK(launch_big_tn_group(g, (hipStream_t)stream, g_op_tn_parts));
+  return 0;
+}
 int fact_op_gemm_tn_group_adam(int n, const void* const* A, const int* lda, const void* const* B, const int* ldb,
                                float* const* p, float* const* m, float* const* v, void* const* sd, const int* lds,
                                void* const* st, const int* ldt, const int* Mo, const int* No, const int* trans, int K,

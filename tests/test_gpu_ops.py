@@ -403,6 +403,50 @@ def test_gemm_tn_group(tn_group_loop, K):
     _close(oq, 2.0 + h1[:, :d].float().t() @ dqkv[:, :3 * d].float(), 1e-3, tol, "dWqkv")
 
 
+@pytest.mark.parametrize("K,parts", [(32, 1), (320, 1), (1920, 2), (5760, 2)])
+def test_gemm_tn_group_operand_column_sums(K, parts):
+    """Round 6 (engine option bias_in_wgrad): the grouped wgrad launch also leaves the column sums over tokens of one operand
+    per problem - the bias gradients of dense_2 (A operand of the transposed-store problem), dense_1 and to_out (B operands) -
+    taken from the MFMA pipe with a ones fragment by the workgroups of the first tile row / column.  Against torch on the
+    bf16 operands (fp32 accumulation either way), accumulation into existing values, ragged widths (800 = 3 x 256 + 32,
+    2400), launch cut in `parts`, weight gradients unchanged by it."""
+    lib = L.lib()
+    g = torch.Generator(device=DEV).manual_seed(33)
+    d, ff, qp, dp, fp = 800, 3072, 2432, 832, 3072
+    def mk(cols, ld):
+        t = torch.full((K, ld), 3.0, device=DEV, dtype=torch.bfloat16)   # pitch padding is NOT zero: must not leak in
+        t[:, :cols] = _bf(torch.randn(K, cols, device=DEV, generator=g))
+        return t
+    xin, gact, h2, dpre, att, xmid, h1, dqkv = (mk(d, dp), mk(ff, fp), mk(d, dp), mk(ff, fp), mk(d, dp),
+                                                mk(d, dp), mk(d, dp), mk(3 * d, qp))
+    outs = [torch.zeros(ff, d, device=DEV), torch.zeros(d, ff, device=DEV), torch.zeros(d, d, device=DEV),
+            torch.zeros(d, 3 * d, device=DEV)]
+    cs = [torch.full((d,), 0.25, device=DEV), torch.full((ff,), -0.5, device=DEV), torch.zeros(d, device=DEV), None]
+    probs = [(xin, d, gact, ff, outs[0], 1), (h2, d, dpre, ff, outs[1], 0), (att, d, xmid, d, outs[2], 0),
+             (h1, d, dqkv, 3 * d, outs[3], 0)]
+    n = 4
+    VP, IA = C.c_void_p * n, C.c_int * n
+    A = VP(*[p[0].data_ptr() for p in probs]); lda = IA(*[p[0].stride(0) for p in probs])
+    B = VP(*[p[2].data_ptr() for p in probs]); ldb = IA(*[p[2].stride(0) for p in probs])
+    out = VP(*[p[4].data_ptr() for p in probs]); ldo = IA(*[p[4].stride(0) for p in probs])
+    Mo = IA(*[p[1] for p in probs]); No = IA(*[p[3] for p in probs]); tr = IA(*[p[5] for p in probs])
+    csp = VP(*[(c.data_ptr() if c is not None else None) for c in cs])
+    lib.fact_debug_gemm_tn_cfg(parts << 8)
+    try:
+        L.check(lib.fact_op_gemm_tn_group_cs(n, A, lda, B, ldb, out, ldo, Mo, No, tr, csp, K, L.cur_stream()))
+        _sync()
+    finally:
+        lib.fact_debug_gemm_tn_cfg(0)
+    tol = 2e-3 * math.sqrt(K)
+    _close(cs[0], 0.25 + xin[:, :d].float().sum(0), 1e-3, tol, "column sums of A (dense_2 bias)")
+    _close(cs[1], -0.5 + dpre[:, :ff].float().sum(0), 1e-3, tol, "column sums of B (dense_1 bias)")
+    _close(cs[2], xmid[:, :d].float().sum(0), 1e-3, tol, "column sums of B (to_out bias)")
+    _close(outs[0], gact[:, :ff].float().t() @ xin[:, :d].float(), 1e-3, tol, "dW2 beside the column sums")
+    _close(outs[1], h2[:, :d].float().t() @ dpre[:, :ff].float(), 1e-3, tol, "dW1 beside the column sums")
+    _close(outs[2], att[:, :d].float().t() @ xmid[:, :d].float(), 1e-3, tol, "dWo beside the column sums")
+    _close(outs[3], h1[:, :d].float().t() @ dqkv[:, :3 * d].float(), 1e-3, tol, "dWqkv")
+
+
 def test_gemm_tn_group_small_dims(tn_group_loop):
     """Other hidden sizes: d = 128 (one partial 160-row tile), d = 1536 (9.6 tiles), single problem."""
     g = torch.Generator(device=DEV).manual_seed(32)
