@@ -1680,7 +1680,7 @@ __global__ __launch_bounds__(768) void attn_bwd_dq_r2_kernel(const AttnParams p)
 
 // dK/dV: 8 waves (2 per SIMD), 32-key slots dealt round-robin; per slot the wave walks the query tiles.
 // The statistics live in LDS negated (-L2, -D): the dP accumulator starts from the loaded -D vector.
-template <int DH, int PK, bool SPLIT = true>
+template <int DH, int PK>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv_r2_kernel(const AttnParams p) {
   using G = Geo<DH>;
   using R = R2<G::DHP>;
@@ -1711,9 +1711,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_r2_kernel(const AttnParams 
   const int nqv = (p.nq > 0 && p.nq < p.n) ? p.nq : p.n;  // valid query rows (supervised-rows shortcut: dO rows >= nq are zero)
   const int nfull = nqv >> 5;  // query tiles without padded / unsupervised rows
   const int b = bh / p.H, h = bh - b * p.H;
-  const int ntl = nfull + ((nqv & 31) ? 1 : 0);  // query tiles that hold valid queries (the last one may be partial)
-  // dK / dV of key slot `slot` over the query tiles [t0, t1) (t1 <= ntl; tile nfull, if in range, is the masked one)
-  auto process = [&](int slot, int t0, int t1, f32x4 (&dK)[2][G::ND], f32x4 (&dV)[2][G::ND]) {
+  for (int slot = wave; slot < nqt; slot += nw) {
     const int key0 = slot * 32;
     bf16x8 Kf[2][G::KD], Vf[2][G::KD];
 #pragma unroll
@@ -1724,6 +1722,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_r2_kernel(const AttnParams 
         Kf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.krow + off);
         Vf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.vrow + off);
       }
+    f32x4 dK[2][G::ND], dV[2][G::ND];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1731,14 +1730,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_r2_kernel(const AttnParams 
         dK[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
         dV[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    const unsigned char* qr = Qimg + rowoff + t0 * R::TILE;
-    const unsigned char* dr = dOimg + rowoff + t0 * R::TILE;
-    const unsigned char* qe = Qimg + trE + t0 * R::TILE;
-    const unsigned char* qo = Qimg + trO + t0 * R::TILE;
-    const unsigned char* de = dOimg + trE + t0 * R::TILE;
-    const unsigned char* dd = dOimg + trO + t0 * R::TILE;
-    const float* st = nL2s + g * 4 + t0 * 32;  // this lane's 4 query rows of a 16-row sub-tile
-    const float* sd = nDs + g * 4 + t0 * 32;
+    const unsigned char* qr = Qimg + rowoff;
+    const unsigned char* dr = dOimg + rowoff;
+    const unsigned char* qe = Qimg + trE;
+    const unsigned char* qo = Qimg + trO;
+    const unsigned char* de = dOimg + trE;
+    const unsigned char* dd = dOimg + trO;
+    const float* st = nL2s + g * 4;  // this lane's 4 query rows of a 16-row sub-tile
+    const float* sd = nDs + g * 4;
     // J: tile inside the group of four the bases point at; MASK: the one tile that holds padded / unsupervised query
     // rows (peeled off the loop: the dO scratch is shared by stacks of different geometry, its padding is not zero)
     auto body = [&](auto jc, auto mc, int qt) {
@@ -1794,26 +1793,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_r2_kernel(const AttnParams 
         }
       }
     };
-    const int tf = t1 < nfull ? t1 : nfull;  // end of the unmasked tiles of the range
-    int at = t0;                             // tile the bases stand at
-    for (int qt = t0; qt < tf; qt += 4) {
+    for (int qt = 0; qt < nfull; qt += 4) {
       body(SlotK<0>{}, SlotK<0>{}, qt);
-      if (qt + 1 < tf) body(SlotK<1>{}, SlotK<0>{}, qt + 1);
-      if (qt + 2 < tf) body(SlotK<2>{}, SlotK<0>{}, qt + 2);
-      if (qt + 3 < tf) body(SlotK<3>{}, SlotK<0>{}, qt + 3);
+      if (qt + 1 < nfull) body(SlotK<1>{}, SlotK<0>{}, qt + 1);
+      if (qt + 2 < nfull) body(SlotK<2>{}, SlotK<0>{}, qt + 2);
+      if (qt + 3 < nfull) body(SlotK<3>{}, SlotK<0>{}, qt + 3);
       qr += 4 * R::TILE; dr += 4 * R::TILE; qe += 4 * R::TILE; qo += 4 * R::TILE; de += 4 * R::TILE; dd += 4 * R::TILE;
       st += 128; sd += 128;
-      at += 4;
     }
-    if (t1 > nfull && t0 <= nfull) {  // the range ends with the partial tile
-      const int back = at - nfull;    // (<= 0 when the range holds nothing else)
+    if (nqv & 31) {
+      const int back = ((nfull + 3) & ~3) - nfull;  // the bases stand at the next multiple of four tiles
       qr -= back * R::TILE; dr -= back * R::TILE; qe -= back * R::TILE; qo -= back * R::TILE; de -= back * R::TILE;
       dd -= back * R::TILE; st -= back * 32; sd -= back * 32;
       body(SlotK<0>{}, SlotK<1>{}, nfull);
     }
-  };
-  auto store = [&](int slot, const f32x4 (&dK)[2][G::ND], const f32x4 (&dV)[2][G::ND]) {
-    const int key0 = slot * 32;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int t = key0 + ks * 16 + (lane & 15);
@@ -1831,46 +1824,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_r2_kernel(const AttnParams 
         }
       }
     }
-  };
-  f32x4 dK[2][G::ND], dV[2][G::ND];
-  // Round 6: 12 key slots (n = 360) on 8 waves used to be two rounds with half the waves idle in the second (24 slot-rounds
-  // of time for 12 slots of work).  When the surplus slots E = nqt - nw fit twice into the waves, every surplus slot is
-  // shared by a PAIR of waves - each takes half of its query tiles - and the pair's partial dK / dV meet in LDS once, after
-  // everyone is done with the Q / dO images (two barriers per kernel): 12 + 6 = 18 tile-units per wave instead of 24.
-  const int surplus = nqt - nw;
-  if (!(SPLIT && surplus > 0 && 2 * surplus <= nw)) {
-    for (int slot = wave; slot < nqt; slot += nw) {
-      process(slot, 0, ntl, dK, dV);
-      store(slot, dK, dV);
-    }
-    return;
-  }
-  process(wave, 0, ntl, dK, dV);
-  store(wave, dK, dV);
-  const bool paired = wave < 2 * surplus;
-  const int slot2 = nw + (wave >> 1), half = wave & 1, tmid = (ntl + 1) >> 1;
-  if (paired) process(slot2, half ? tmid : 0, half ? ntl : tmid, dK, dV);
-  __syncthreads();  // nobody reads the Q / dO images any more: they become the exchange area
-  f32x4* xch = reinterpret_cast<f32x4*>(smem) + (size_t)(wave >> 1) * (4 * G::ND * 64) + lane;  // [pair][2 * 2 * ND][64 lanes]
-  if (paired && half) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int dt = 0; dt < G::ND; ++dt) {
-        xch[((ks * G::ND + dt) * 2 + 0) * 64] = dK[ks][dt];
-        xch[((ks * G::ND + dt) * 2 + 1) * 64] = dV[ks][dt];
-      }
-  }
-  __syncthreads();
-  if (paired && !half) {
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int dt = 0; dt < G::ND; ++dt) {
-        dK[ks][dt] += xch[((ks * G::ND + dt) * 2 + 0) * 64];
-        dV[ks][dt] += xch[((ks * G::ND + dt) * 2 + 1) * 64];
-      }
-    store(slot2, dK, dV);
   }
 }
 
@@ -1880,8 +1833,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_r2_kernel(const AttnParams 
 // it the CUs - same-box A/B of the step: 7.97-7.99 / 7.94-7.95 / 7.87-7.90 / 8.00-8.01 ms for 1 / 2 / 3 / 4), 4 = the reverse,
 // 5 (default, round 4) = streaming forward + LEAN resident backward (kernels above: dQ 30.0 -> 26.9 us, dK/dV 32.9 -> 26.7 us
 // alone, 38.2 -> 32.5 us per launch in the step, step 7.64 -> 7.58 ms same box), 6 = resident forward + lean backward,
-// 7 / 8 = 5 / 6 with packed fp32 softmax arithmetic (28.1 / 27.8 us: v_pk_* issue half as often but run twice as long),
-// 9 = 5 with the round-4/5 dK/dV slot loop (round 6 default: surplus key slots shared by wave pairs, attn_bwd_dkdv_r2_kernel)
+// 7 / 8 = 5 / 6 with packed fp32 softmax arithmetic (28.1 / 27.8 us: v_pk_* issue half as often but run twice as long)
 int g_attn_variant = 5;
 int g_attn_force_tiled = 0;  // test knob: 1 = always use the tiled (streaming) kernels
 
@@ -1943,7 +1895,7 @@ bool bwd_is_resident(int n) {
 template <int DH>
 int fwd_t(const AttnParams& p, hipStream_t s) {
   // streaming kernel: the default forward; also whatever the resident kernels cannot hold (head dims above 96, n > 384)
-  if ((g_attn_variant == 2 || g_attn_variant == 3 || g_attn_variant == 5 || g_attn_variant == 7 || g_attn_variant == 9 ||
+  if ((g_attn_variant == 2 || g_attn_variant == 3 || g_attn_variant == 5 || g_attn_variant == 7 ||
        !res_lds_bytes<DH>(p.n, 0)) &&
       !g_attn_force_tiled) {
     constexpr size_t lds = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG;
@@ -1991,7 +1943,7 @@ int bwd_t(const AttnParams& p, hipStream_t s) {
   const int nw = ((p.n + 31) & ~31) / 32;
   dim3 grid((p.n + 127) / 128, p.B * p.H);
   if constexpr (DH <= 96) {
-    const bool r2 = g_attn_variant >= 5, pk = (g_attn_variant == 7 || g_attn_variant == 8), nosplit = (g_attn_variant == 9);
+    const bool r2 = g_attn_variant >= 5, pk = g_attn_variant >= 7;
     if (lds1 && r2 && pk) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dq_r2_kernel<DH, 1>, &attr)) return rc;
@@ -2011,10 +1963,6 @@ int bwd_t(const AttnParams& p, hipStream_t s) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 1>, &attr)) return rc;
       FACT_LAUNCH((attn_bwd_dkdv_r2_kernel<DH, 1>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
-    } else if (lds2 && r2 && nosplit) {  // A/B: the round-4/5 slot loop (12 key slots on 8 waves = two rounds)
-      static bool attr = false;
-      if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 0, false>, &attr)) return rc;
-      FACT_LAUNCH((attn_bwd_dkdv_r2_kernel<DH, 0, false>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
     } else if (lds2 && r2) {
       static bool attr = false;
       if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 0>, &attr)) return rc;

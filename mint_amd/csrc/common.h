@@ -12,6 +12,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -20,6 +21,13 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 DEVINL f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// v_mfma_f32_32x32x16_bf16 (round 6, the N = 3072 / 2400 NT GEMMs):
+//   A fragment: lane l holds A[i = l&31][k = (l>>5)*8 + j], j = 0..7;  B fragment: B[k = (l>>5)*8 + j][n = l&31]
+//   C/D       : lane l holds D[row = 8*(r>>2) + 4*(l>>5) + (r&3)][col = l&31], r = 0..15
+DEVINL f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
 DEVINL bf16x8 zero_bf16x8() {

@@ -85,7 +85,8 @@ constexpr int kSplitKCounters = 1024;
 enum BigCfgId : int { BIG_288x256 = 0, BIG_256x256 = 1, BIG_256x160 = 2, BIG_160x256 = 3, BIG_256x128 = 4,
                       BIG_256x160_K64 = 5, BIG_288x256_K64 = 6, BIG_256x256_K64 = 7 /* 64-deep ring slots (whole-line DMA pieces) */,
                       BIG_192x160_K64 = 8 /* round 4: 150 instead of 115 tiles for the whole-K N = 800 dgrads at M = 5760 */,
-                      BIG_128x160 = 9 /* round 5: short-K N = 800 GEMMs as 225 tiles, two workgroups per CU */ };
+                      BIG_128x160 = 9 /* round 5: short-K N = 800 GEMMs as 225 tiles, two workgroups per CU */,
+                      BIG_256x256_M32 = 10, BIG_384x192_M32 = 11 /* round 6: v_mfma_f32_32x32x16_bf16 tiles on 64-deep slots (wave tile 128x64 / 96x96) */ };
 int big_tile_dims(int cfg, int* bm, int* bn);
 // NT GEMM on a given tile config (K % 32 == 0, splitk == 1); fused epilogues as above.
 int launch_big_nt(int cfg, int epi, const GemmParams& p, hipStream_t stream);

@@ -958,6 +958,8 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
     if (variant == 19) cfg = k64_ok ? BIG_256x256_K64 : BIG_256x256;
     if (variant == 20) cfg = BIG_192x160_K64;
     if (variant == 21) cfg = BIG_128x160;
+    if (variant == 22) cfg = k64_ok ? BIG_256x256_M32 : BIG_256x256;   // 32 x 32 x 16 MFMA tiles (round 6)
+    if (variant == 23) cfg = k64_ok ? BIG_384x192_M32 : BIG_288x256;
     if (variant == 0 && g_tile128x160 && cfg == BIG_256x128 && p.N % 160 == 0 && p.N <= 960 && p.K < 1536 &&
         (EPI == EPI_F32_BIAS_RESID || EPI == EPI_HEADS || EPI == EPI_BF16))
       cfg = BIG_128x160;  // the SHORT-K N = 800 GEMMs on 128x160 tiles (long K: the tile loses, profiles/r05_tile128x160_long_k.txt)

@@ -19,6 +19,7 @@
 // columns; a problem flagged `trans_out` (dW stored as [n][m]) uses the un-swapped roles instead, which
 // leaves 4 consecutive m per lane = 16 contiguous bytes of the transposed output.
 #include "gemm.h"
+#include <type_traits>
 
 namespace {
 
@@ -53,10 +54,25 @@ DEVINL bf16x4 tr_read(unsigned addr) {
   return r;
 }
 
-template <int WGM_, int MR_, int WGN_, int NR_, int NSTAGE_ = 4, int WGS_PER_CU_ = 1, int KS_ = 32>
+// MF (round 6): MFMA shape of the NT kernels - 16 = v_mfma_f32_16x16x32_bf16 (MR x NR tiles of 16 x 16 per wave), 32 =
+// v_mfma_f32_32x32x16_bf16 (MR x NR tiles of 32 x 32; 64-deep ring slots only): 32 x 32 x 16 issues in 32 cycles for twice the
+// FLOPs of a 17-19-cycle 16 x 16 x 32 (tools/mfma_rate_probe.hip: 2 068 vs 1 889 TFLOP/s chip-wide).  Accumulator layout of the
+// 32 x 32 form (swapped roles: rows of D = output columns n): lane = output row m = lane & 31, register 4 q + r = output
+// column 8 q + 4 (lane >> 5) + r - four QUADS of 4 consecutive columns per tile where the 16 x 16 form has one.
+template <int WGM_, int MR_, int WGN_, int NR_, int NSTAGE_ = 4, int WGS_PER_CU_ = 1, int KS_ = 32, int MF_ = 16>
 struct BigCfg {
-  static constexpr int WGM = WGM_, MR = MR_, WGN = WGN_, NR = NR_;
-  static constexpr int BM = WGM * MR * 16, BN = WGN * NR * 16;
+  static constexpr int WGM = WGM_, MR = MR_, WGN = WGN_, NR = NR_, MF = MF_;
+  static_assert(MF == 16 || (MF == 32 && KS_ == 64), "MFMA shape");
+  static constexpr int BM = WGM * MR * MF, BN = WGN * NR * MF;
+  static constexpr int WROWS = MR * MF, WCOLS = NR * MF;  // wave tile
+  static constexpr int NQ = NR * ((MF == 32) ? 4 : 1);  // quads of 4 consecutive columns per accumulator row: NR (16) / 4 NR (32)
+  static constexpr int QPT = (MF == 32) ? 4 : 1;                   // quads per tile
+  using AccT = std::conditional_t<MF == 32, f32x16, f32x4>;       // accumulator of one MFMA tile
+  // first column (inside the wave tile) of quad jq for this lane; the lane's row inside a row tile is lane & (MF - 1)
+  __device__ __forceinline__ static int qcol(int jq, int lane) {
+    if constexpr (MF == 32) return (jq >> 2) * 32 + (jq & 3) * 8 + (lane >> 5) * 4;
+    else return jq * 16 + (lane >> 4) * 4;
+  }
   static constexpr int NSTAGE = NSTAGE_, DIST = NSTAGE - 1;
   static constexpr int WGS_PER_CU = WGS_PER_CU_;  // co-resident workgroups the register / LDS budget is sized for
   // KS = depth of a ring slot along K.  32 (rounds 1-2): a 1 KiB DMA piece is 16 rows x 64 B - HALF a 128-byte line per
@@ -570,7 +586,7 @@ DEVINL void tn_mainloop_pf(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
 template <class C, bool SWAP>
 DEVINL void big_mainloop64(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1], const unsigned (&sadv)[C::LPS_LO + 1],
                            const unsigned (&voff)[C::LPS_LO + 1], const int (&dst)[C::LPS_LO + 1], int nk32, int wave,
-                           int wm, int wn, int lane, f32x4 (&acc)[C::MR][C::NR]) {
+                           int wm, int wn, int lane, typename C::AccT (&acc)[C::MR][C::NR]) {
   constexpr int MR = C::MR, NR = C::NR, NST = C::NSTAGE, STAGE = C::STAGE_BYTES, D = NST - 1;
   constexpr int LPS_LO = C::LPS_LO, EXTRA = C::EXTRA;
   static_assert(C::KS == 64 && (NST == 2 || NST == 3), "64-deep slots on a 2- or 3-slot ring");
@@ -605,17 +621,28 @@ DEVINL void big_mainloop64(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
       wait_vmcnt<0>();
     }
   };
+  constexpr int MF = C::MF, TILEB = MF * 128;  // bytes of one row tile of the stage image (MF rows x one 128-byte line)
+  constexpr int SUBS = (MF == 32) ? 2 : 1;     // MFMA K sub-steps per 32-deep multiply step (32 x 32 x 16: two of 16)
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
-    for (int j = 0; j < NR; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NR; ++j) acc[i][j] = typename C::AccT{};
 
-  // fragment addresses: row r = lane & 15 of a 16-row tile (2 KiB), chunk 4 ks + (lane >> 4)
-  const int r = lane & 15, cq = lane >> 4;
-  unsigned lp[2];
-  lp[0] = (unsigned)(r * 128 + (((0 + cq) ^ (r & 7)) << 4));
-  lp[1] = (unsigned)(r * 128 + (((4 + cq) ^ (r & 7)) << 4));
-  const unsigned a_base = (unsigned)(wm * MR * 2048), b_base = (unsigned)(C::A_BYTES + wn * NR * 2048);
+  // fragment addresses.  16 x 16 x 32: row r = lane & 15 of a 16-row tile (2 KiB), chunk 4 ks + (lane >> 4), image position
+  // chunk ^ (r & 7).  32 x 32 x 16: row r = lane & 31 of a 32-row tile (4 KiB), chunk 2 sub + (lane >> 5) for K sub-step
+  // sub = 0..3 of the slot, image position chunk ^ ((r >> 1) & 7): the 16 lanes of every ds_read_b128 service group
+  // ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and their upper halves) then fall on 16 distinct 16-byte bank slots.
+  unsigned lp[2 * SUBS];
+  if constexpr (MF == 32) {
+    const int r = lane & 31, hf = lane >> 5, gsw = (r >> 1) & 7;
+#pragma unroll
+    for (int sb = 0; sb < 4; ++sb) lp[sb] = (unsigned)(r * 128 + (((2 * sb + hf) ^ gsw) << 4));
+  } else {
+    const int r = lane & 15, cq = lane >> 4;
+    lp[0] = (unsigned)(r * 128 + (((0 + cq) ^ (r & 7)) << 4));
+    lp[1] = (unsigned)(r * 128 + (((4 + cq) ^ (r & 7)) << 4));
+  }
+  const unsigned a_base = (unsigned)(wm * MR * TILEB), b_base = (unsigned)(C::A_BYTES + wn * NR * TILEB);
 
   issue(SlotC<0>{}, SlotC<0>{}, 1 < nst);
   issue(SlotC<0>{}, SlotC<1>{}, 1 < nst);
@@ -626,15 +653,18 @@ DEVINL void big_mainloop64(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
   wait_landed();
   __builtin_amdgcn_s_barrier();  // stage 0 landed
 
-  bf16x8 af[MR], bfr[NR];
+  bf16x8 af[SUBS][MR], bfr[SUBS][NR];
   auto body = [&](auto slot_c, auto ks_c, int t) {
     constexpr int SLOT = decltype(slot_c)::value, KSI = decltype(ks_c)::value;
     constexpr int NEXT = (SLOT + D) % NST;  // slot of stage t + D (= the slot stage t - 1 used)
     const unsigned char* st = smem + SLOT * STAGE;
 #pragma unroll
-    for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * 2048 + lp[KSI]);
+    for (int sb = 0; sb < SUBS; ++sb) {
 #pragma unroll
-    for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * 2048 + lp[KSI]);
+      for (int j = 0; j < NR; ++j) bfr[sb][j] = *reinterpret_cast<const bf16x8*>(st + b_base + j * TILEB + lp[KSI * SUBS + sb]);
+#pragma unroll
+      for (int i = 0; i < MR; ++i) af[sb][i] = *reinterpret_cast<const bf16x8*>(st + a_base + i * TILEB + lp[KSI * SUBS + sb]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (D == 2) {
       issue(SlotC<NEXT>{}, SlotC<KSI>{}, t + D + 1 < nst);
@@ -646,10 +676,14 @@ DEVINL void big_mainloop64(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int i = 0; i < MR; ++i)
+    for (int sb = 0; sb < SUBS; ++sb)
 #pragma unroll
-      for (int j = 0; j < NR; ++j)
-        acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          if constexpr (MF == 32) acc[i][j] = SWAP ? mfma32(bfr[sb][j], af[sb][i], acc[i][j]) : mfma32(af[sb][i], bfr[sb][j], acc[i][j]);
+          else acc[i][j] = SWAP ? mfma16(bfr[sb][j], af[sb][i], acc[i][j]) : mfma16(af[sb][i], bfr[sb][j], acc[i][j]);
+        }
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_s_barrier();
   };
@@ -727,25 +761,26 @@ constexpr bool kStagedF32 = (EPI == EPI_F32_BIAS || EPI == EPI_F32_BIAS_RESID);
 template <int EPI>
 DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f32x4 v);
 
-// accumulator rows (16-row MFMA tiles) per pass of the staged fp32 epilogue: the largest divisor of MR whose 8 wave regions fit
+// accumulator rows (MF-row MFMA tiles) per pass of the staged fp32 epilogue: the largest divisor of MR whose 8 wave regions fit
 // the idle ring (shared by the epilogue and the symmetric split-K finish, which hands each slice whole passes)
 template <class C>
 constexpr int f32_pass_rows() {
-  constexpr int MR = C::MR, STR = C::NR * 64 + 16;
-  return (C::NW * MR * 16 * STR <= C::LDS_BYTES)                          ? MR
-         : (MR % 2 == 0 && C::NW * (MR / 2) * 16 * STR <= C::LDS_BYTES)  ? MR / 2
-         : (MR % 3 == 0 && C::NW * (MR / 3) * 16 * STR <= C::LDS_BYTES)  ? MR / 3
-         : (MR % 4 == 0 && C::NW * (MR / 4) * 16 * STR <= C::LDS_BYTES)  ? MR / 4
+  constexpr int MR = C::MR, RT = C::MF, STR = C::WCOLS * 4 + 16;
+  return (C::NW * MR * RT * STR <= C::LDS_BYTES)                          ? MR
+         : (MR % 2 == 0 && C::NW * (MR / 2) * RT * STR <= C::LDS_BYTES)  ? MR / 2
+         : (MR % 3 == 0 && C::NW * (MR / 3) * RT * STR <= C::LDS_BYTES)  ? MR / 3
+         : (MR % 4 == 0 && C::NW * (MR / 4) * RT * STR <= C::LDS_BYTES)  ? MR / 4
                                                                         : 1;
 }
 
 template <class C, int EPI>
 __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(const GemmParams p) {
-  constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN;
+  constexpr int MR = C::MR, NR = C::NR, BM = C::BM, BN = C::BN, NQ = C::NQ, RT = C::MF;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / C::WGN, wn = wave % C::WGN;
+  const int lrow_t = lane & (RT - 1);  // this lane's row inside a row tile of the accumulator
 
   const int tn = (p.N + BN - 1) / BN, tm = (p.M + BM - 1) / BM;
   int m0, n0;
@@ -775,11 +810,14 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     // 64-deep slots: 8 rows x 128 B (lane -> row lane >> 3, chunk (lane & 7) ^ row)
     constexpr int PR = C::PROWS;
     const int lrow = (C::KS == 64) ? (lane >> 3) : (lane >> 2);
-    const int lchunk = (C::KS == 64) ? ((lane & 7) ^ lrow) : ((lane & 3) ^ ring_g(lrow));
+    const int lchunk16 = (C::KS == 64) ? ((lane & 7) ^ lrow) : ((lane & 3) ^ ring_g(lrow));
+    static_assert(C::MF == 16 || (C::A_PIECES % 4 == 0 && C::B_PIECES % 4 == 0), "32-row tiles = 4 DMA pieces");
 #pragma unroll
     for (int i = 0; i < C::LPS_LO + 1; ++i) {
       const int q = (i < C::LPS_LO) ? wave * C::LPS_LO + i : C::NW * C::LPS_LO + wave;  // extras: pieces NW*LPS_LO..
       const int qq = min(q, C::NPIECE - 1);
+      // 32 x 32 x 16 image: row r of a 32-row tile keeps chunk c at position c ^ ((r >> 1) & 7); r = (piece & 3) * 8 + lrow
+      const int lchunk = (C::MF == 32) ? ((lane & 7) ^ (((qq & 1) << 2) | (lrow >> 1))) : lchunk16;
       if (qq < C::A_PIECES) {  // wave-uniform
         sptr[i] = reinterpret_cast<const char*>(p.A) + (size_t)k_beg * 64;
         voff[i] = ((unsigned)min(m0 + qq * PR + lrow, p.M - 1) * (unsigned)p.lda + lchunk * 8) * 2u;
@@ -792,9 +830,28 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
       sadv[i] = (C::KS == 64) ? 128 : 64;  // bytes along K per stage
     }
   }
-  f32x4 acc[MR][NR];
+  typename C::AccT acc[MR][NR];
   if constexpr (C::KS == 64) big_mainloop64<C, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
   else big_mainloop<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
+  // quad jq of accumulator row i: 4 consecutive output columns C::qcol(jq, lane).. of output row i * RT + lrow_t
+  auto quad = [&](int i, int jq) -> f32x4 {
+    if constexpr (C::MF == 32) {
+      const f32x16& t = acc[i][jq >> 2];
+      const int q = (jq & 3) * 4;
+      return f32x4{t[q], t[q + 1], t[q + 2], t[q + 3]};
+    } else {
+      return acc[i][jq];
+    }
+  };
+  auto add_quad = [&](int i, int jq, f32x4 v) {
+    if constexpr (C::MF == 32) {
+      f32x16& t = acc[i][jq >> 2];
+      const int q = (jq & 3) * 4;
+      t[q] += v[0]; t[q + 1] += v[1]; t[q + 2] += v[2]; t[q + 3] += v[3];
+    } else {
+      acc[i][jq] += v;
+    }
+  };
 
   // rows of the wave tile this workgroup runs the epilogue for: all (-1), or - symmetric 2-way split-K finish - the
   // accumulator rows i < MR / 2 (0) or i >= MR / 2 (1)
@@ -818,7 +875,7 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     // +1 on arrival (wait for >= 2), +1 when the peer's data has been read; the 4th increment returns it to zero.
     constexpr unsigned WG_BYTES = (unsigned)BM * BN * 4;
     char* tile_slabs = reinterpret_cast<char*>(p.sk_slab) + (size_t)tile * p.splitk * WG_BYTES;
-    const unsigned lane_off = (unsigned)(wave * MR * NR * 1024 + lane * 16);
+    const unsigned lane_off = (unsigned)(wave * MR * NQ * 1024 + lane * 16);
     // epilogue passes of <= MR / 2 rows that never straddle the halves: the staged fp32 epilogue below runs CH = kF32PassRows
     // accumulator rows per pass, and a slice must own whole passes
     constexpr int CHF = f32_pass_rows<C>();
@@ -831,9 +888,9 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
       for (int i = 0; i < MR; ++i) {
         if (sym && ((i >= MR / 2) != (z == 0))) continue;  // (wave-uniform) only the rows the peer will finish
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), mine,
-                                                 lane_off + (i * NR + j) * 1024, 0, /*sc1*/ 16);
+        for (int j = 0; j < NQ; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, quad(i, j)), mine,
+                                                 lane_off + (i * NQ + j) * 1024, 0, /*sc1*/ 16);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
@@ -855,12 +912,12 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
         if ((i >= MR / 2) != (z == 1)) continue;  // my rows: i < MR / 2 for slice 0
-        u32x4 t[NR];
+        u32x4 t[NQ];
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
-          t[j] = __builtin_amdgcn_raw_buffer_load_b128(peer, lane_off + (i * NR + j) * 1024, 0, /*sc1*/ 16);
+        for (int j = 0; j < NQ; ++j)
+          t[j] = __builtin_amdgcn_raw_buffer_load_b128(peer, lane_off + (i * NQ + j) * 1024, 0, /*sc1*/ 16);
 #pragma unroll
-        for (int j = 0; j < NR; ++j) acc[i][j] += __builtin_bit_cast(f32x4, t[j]);
+        for (int j = 0; j < NQ; ++j) add_quad(i, j, __builtin_bit_cast(f32x4, t[j]));
       }
       __syncthreads();  // every wave holds its peer data (the loads above were waited for by the adds)
       if (tid == 0) {
@@ -885,12 +942,12 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
             __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)zz * WG_BYTES, 0, WG_BYTES, 0x00020000);
 #pragma unroll
         for (int i = 0; i < MR; ++i) {
-          u32x4 t[NR];
+          u32x4 t[NQ];
 #pragma unroll
-          for (int j = 0; j < NR; ++j)
-            t[j] = __builtin_amdgcn_raw_buffer_load_b128(peer, lane_off + (i * NR + j) * 1024, 0, /*sc1*/ 16);
+          for (int j = 0; j < NQ; ++j)
+            t[j] = __builtin_amdgcn_raw_buffer_load_b128(peer, lane_off + (i * NQ + j) * 1024, 0, /*sc1*/ 16);
 #pragma unroll
-          for (int j = 0; j < NR; ++j) acc[i][j] += __builtin_bit_cast(f32x4, t[j]);
+          for (int j = 0; j < NQ; ++j) add_quad(i, j, __builtin_bit_cast(f32x4, t[j]));
         }
       }
       __syncthreads();  // flag word read by everyone before the ring is reused as epilogue staging
@@ -898,18 +955,19 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
   }
 
   const EpiParams& ep = p.ep;
-  const int wrow0 = m0 + wm * (16 * MR), wcol0 = n0 + wn * (16 * NR);
+  const int wrow0 = m0 + wm * C::WROWS, wcol0 = n0 + wn * C::WCOLS;
   if constexpr (kStagedBf16<EPI>) {
     constexpr int NOUT = (EPI == EPI_BIAS_GELU) ? 2 : 1;
-    constexpr int ROWB = NR * 32, STR = ROWB + 16, CPR = ROWB / 16;  // bf16 staging row, chunks per row
+    constexpr int ROWB = C::WCOLS * 2, STR = ROWB + 16, CPR = ROWB / 16;  // bf16 staging row, chunks per row
     // rows per pass: largest divisor CH of MR whose 8 wave regions fit the ring
-    constexpr int CH = (C::NW * NOUT * MR * 16 * STR <= C::LDS_BYTES)                             ? MR
-                       : (MR % 2 == 0 && C::NW * NOUT * (MR / 2) * 16 * STR <= C::LDS_BYTES)     ? MR / 2
-                       : (MR % 3 == 0 && C::NW * NOUT * (MR / 3) * 16 * STR <= C::LDS_BYTES)     ? MR / 3
-                       : (MR % 4 == 0 && C::NW * NOUT * (MR / 4) * 16 * STR <= C::LDS_BYTES)     ? MR / 4
+    constexpr int CH = (C::NW * NOUT * MR * RT * STR <= C::LDS_BYTES)                             ? MR
+                       : (MR % 2 == 0 && C::NW * NOUT * (MR / 2) * RT * STR <= C::LDS_BYTES)     ? MR / 2
+                       : (MR % 3 == 0 && C::NW * NOUT * (MR / 3) * RT * STR <= C::LDS_BYTES)     ? MR / 3
+                       : (MR % 4 == 0 && C::NW * NOUT * (MR / 4) * RT * STR <= C::LDS_BYTES)     ? MR / 4
                                                                                               : 1;
-    constexpr int REG = CH * 16 * STR;
-    constexpr int TOT = CH * 16 * CPR, IT = (TOT + 63) / 64;  // 16-byte chunks of one pass, per-lane trips
+    static_assert(C::NW * NOUT * CH * RT * STR <= C::LDS_BYTES, "one pass of the bf16 staging fits the ring");
+    constexpr int REG = CH * RT * STR;
+    constexpr int TOT = CH * RT * CPR, IT = (TOT + 63) / 64;  // 16-byte chunks of one pass, per-lane trips
     bool aligned = !(p.N & 7) && (NOUT == 1 || !(ep.ldo1 & 7)) && (EPI != EPI_GELU_BWD || !(ep.ldp & 7));
     if constexpr (EPI == EPI_HEADS) aligned = aligned && !(ep.dh & 7) && !(ep.dhp & 7);
     else aligned = aligned && !(ep.ldo0 & 7);
@@ -920,7 +978,7 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
       bf16_t* h2 = ep.hrow[2];
 #pragma unroll
       for (int c = 0; c < MR / CH; ++c) {
-        const int prow0 = wrow0 + c * CH * 16;
+        const int prow0 = wrow0 + c * CH * RT;
         if constexpr (EPI == EPI_GELU_BWD) {
           // the saved pre-activation comes in the way the result goes out: whole row segments into the
           // staging image, then each lane picks its 4 values at the offset it will overwrite
@@ -943,12 +1001,12 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
 #pragma unroll
         for (int ii = 0; ii < CH; ++ii) {
           const int i = c * CH + ii;
-          const int lr = ii * 16 + (lane & 15);
+          const int lr = ii * RT + lrow_t;
 #pragma unroll
-          for (int j = 0; j < NR; ++j) {
-            const int lc = j * 16 + (lane >> 4) * 4;
+          for (int j = 0; j < NQ; ++j) {
+            const int lc = C::qcol(j, lane);
             const int col = wcol0 + lc;
-            const f32x4 v = acc[i][j];
+            const f32x4 v = quad(i, j);
             const int off = lr * STR + lc * 2;
             bf16x4 o0, o1;
             if constexpr (EPI == EPI_BF16 || EPI == EPI_HEADS) {
@@ -996,10 +1054,11 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     }
   }
   if constexpr (kStagedF32<EPI>) {
-    constexpr int ROWB = NR * 64, STR = ROWB + 16, CPR = ROWB / 16;
+    constexpr int ROWB = C::WCOLS * 4, STR = ROWB + 16, CPR = ROWB / 16;
     constexpr int CH = f32_pass_rows<C>();
-    constexpr int REG = CH * 16 * STR;
-    constexpr int TOT = CH * 16 * CPR, IT = (TOT + 63) / 64;
+    static_assert(C::NW * CH * RT * STR <= C::LDS_BYTES, "one pass of the fp32 staging fits the ring");
+    constexpr int REG = CH * RT * STR;
+    constexpr int TOT = CH * RT * CPR, IT = (TOT + 63) / 64;
     const bool aligned = !(p.N & 3) && !(ep.ldo0 & 3) && (EPI != EPI_F32_BIAS_RESID || !(ep.ldr & 3));
     if (aligned) {
       unsigned char* stg = smem + wave * REG;
@@ -1008,7 +1067,7 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
         // symmetric split-K finish: only the passes of this slice's accumulator rows (CH <= MR / 2 there: a pass never
         // straddles the halves)
         if (epi_half >= 0 && ((c * CH >= MR / 2) != (epi_half == 1))) continue;
-        const int prow0 = wrow0 + c * CH * 16;
+        const int prow0 = wrow0 + c * CH * RT;
         // the fp32 residual rows of this pass are requested first, whole row segments per wave load; their
         // latency hides behind the accumulator -> LDS re-shape below
         float4 rv[IT];
@@ -1025,12 +1084,11 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
         }
 #pragma unroll
         for (int ii = 0; ii < CH; ++ii) {
-          const int lr = ii * 16 + (lane & 15);
+          const int lr = ii * RT + lrow_t;
 #pragma unroll
-          for (int j = 0; j < NR; ++j) {
-            const f32x4 v = acc[c * CH + ii][j];
-            *reinterpret_cast<float4*>(stg + lr * STR + (j * 16 + (lane >> 4) * 4) * 4) =
-                make_float4(v[0], v[1], v[2], v[3]);
+          for (int j = 0; j < NQ; ++j) {
+            const f32x4 v = quad(c * CH + ii, j);
+            *reinterpret_cast<float4*>(stg + lr * STR + C::qcol(j, lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
           }
         }
 #pragma unroll
@@ -1058,8 +1116,8 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
   for (int i = 0; i < MR; ++i) {
     if (epi_half >= 0 && ((i >= MR / 2) != (epi_half == 1))) continue;
 #pragma unroll
-    for (int j = 0; j < NR; ++j)
-      direct_store<EPI>(ep, p.M, p.N, wrow0 + i * 16 + (lane & 15), wcol0 + j * 16 + (lane >> 4) * 4, acc[i][j]);
+    for (int j = 0; j < NQ; ++j)
+      direct_store<EPI>(ep, p.M, p.N, wrow0 + i * RT + lrow_t, wcol0 + C::qcol(j, lane), quad(i, j));
   }
 }
 
@@ -1486,6 +1544,13 @@ using Cfg192x160k64 = BigCfg<4, 3, 2, 5, 3, 1, 64>;
 // residual epilogue of the K = 800 out-projection then streams from 225 CUs instead of 161 (nt variant 21; default for the
 // short-K N = 800 GEMMs since round 5, gemm.hip g_tile128x160)
 using Cfg128x160 = BigCfg<4, 2, 2, 5, 3, 2>;
+// Round 6: v_mfma_f32_32x32x16_bf16 tiles (BigCfg::MF = 32; MR / NR count 32 x 32 tiles), two 64-deep ring slots.
+//   256x256: wave grid 2 x 4, wave tile 128 x 64 = 4 x 2 tiles (the 16 x 16 config's geometry, for like-for-like A/Bs)
+//   384x192: wave grid 4 x 2, wave tile  96 x 96 = 3 x 3 tiles: M = 5760 = 15 x 384 and N = 3072 = 16 x 192 -> 240 tiles, the
+//            count (and area) of 288x256, which has no 32-row decomposition on 8 waves (288 = 9 x 32); 6 fragment reads per 9
+//            MFMAs of 32 x 32 x 16 (288x256: 13 per 36 of 16 x 16 x 32 = 6.5 per 9), 72 KiB per slot (68)
+using Cfg256x256m32 = BigCfg<2, 4, 4, 2, 2, 1, 64, 32>;
+using Cfg384x192m32 = BigCfg<4, 3, 2, 3, 2, 1, 64, 32>;
 // (the same tile for the LONG-K N = 800 GEMMs, whole K, 225 workgroups: FFN2 + residual 44.9 us against 40.3 us for 256x160
 //  with the symmetric split-K; whole-K dgrads 40.2 vs 42.3 us; on two 64-deep slots 1-4 us slower still -
 //  profiles/r05_tile128x160_long_k.txt.  Not used there.)
@@ -1500,6 +1565,8 @@ int launch_big_nt_epi(int cfg, const GemmParams& p, hipStream_t s) {
     case BIG_256x160_K64: return launch_big_nt_cfg<Cfg256x160k64, EPI>(p, s);
     case BIG_288x256_K64: return launch_big_nt_cfg<Cfg288x256k64, EPI>(p, s);
     case BIG_256x256_K64: return launch_big_nt_cfg<Cfg256x256k64, EPI>(p, s);
+    case BIG_256x256_M32: return launch_big_nt_cfg<Cfg256x256m32, EPI>(p, s);
+    case BIG_384x192_M32: return launch_big_nt_cfg<Cfg384x192m32, EPI>(p, s);
     case BIG_192x160_K64:
       if constexpr (EPI == EPI_BF16) return launch_big_nt_cfg<Cfg192x160k64, EPI>(p, s);  // the dgrad epilogue only
       else return -7;
@@ -1526,6 +1593,8 @@ int big_tile_dims(int cfg, int* bm, int* bn) {
     case BIG_256x256_K64: *bm = 256; *bn = 256; return 0;
     case BIG_192x160_K64: *bm = 192; *bn = 160; return 0;
     case BIG_128x160: *bm = 128; *bn = 160; return 0;
+    case BIG_256x256_M32: *bm = 256; *bn = 256; return 0;
+    case BIG_384x192_M32: *bm = 384; *bn = 192; return 0;
   }
   return -1;
 }

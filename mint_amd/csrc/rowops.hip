@@ -1190,10 +1190,9 @@ int launch_col_tasks(ColTasks ts, hipStream_t s) {
     t.cgw = even ? ((((t.C + ng - 1) / ng) + 3) & ~3) : 256;  // even column groups: 800 -> 4 x 200 (not 3 x 256 + 32: an eighth-filled group)
     groups += ng;
   }
-  // rows per workgroup: 128 with the bias tasks in the launch (20 column groups x 45 row blocks at M = 5760); the two LayerNorm tasks
-  // alone (round 6: the bias sums left for the wgrad launch) are 8 column groups - 64 rows keep ~720 workgroups in flight
-  static const int rpb_env = getenv("FACT_COL_RPB") ? atoi(getenv("FACT_COL_RPB")) : 0;  // A/B knob
-  ts.rpb = rpb_env > 0 ? rpb_env : (groups <= 10 ? 64 : 128);
+  // rows per workgroup.  Round 6 A/B with only the two LayerNorm tasks left in the launch (bias_in_wgrad): 64 rows (720 workgroups)
+  // make this kernel 42 -> 32 us and the dgrad GEMMs beside it 2-4 us slower each - step unchanged (profiles/r06_ab_col_rpb.txt)
+  ts.rpb = 128;
   FACT_LAUNCH(col_tasks_kernel, dim3(groups, (ts.M + ts.rpb - 1) / ts.rpb), dim3(256), 0, s, ts);
   return 0;
 }

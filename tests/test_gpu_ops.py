@@ -104,9 +104,9 @@ def gemm_path(request):
     L.lib().fact_debug_force_generic_gemm(0)
 
 
-@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14, 17, 18, 19],
+@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14, 17, 18, 19, 22, 23],
                 ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160", "big256x128x2",
-                     "big256x160k64", "big288x256k64", "big256x256k64"])
+                     "big256x160k64", "big288x256k64", "big256x256k64", "m32_256x256", "m32_384x192"])
 def nt_variant(request):
     """NT kernel choice: the engine's automatic pick, the 128x128 kernel, the round-1 big-tile kernels and
     every tile config of the big-tile family (gemm_big.hip), forced regardless of the tile-count heuristic."""
@@ -213,7 +213,7 @@ def test_gemm_nt_splitk_symmetric_finish(M, N, K):
 
 @pytest.mark.parametrize("M,N,K", [(5760, 800, 3072), (5760, 800, 2400), (700, 800, 800), (300, 500, 96), (256, 160, 32),
                                    (257, 161, 64), (1920, 800, 3072), (64, 72, 160)])
-@pytest.mark.parametrize("variant", [17, 18, 19], ids=["256x160", "288x256", "256x256"])
+@pytest.mark.parametrize("variant", [17, 18, 19, 22, 23], ids=["256x160", "288x256", "256x256", "m32_256x256", "m32_384x192"])
 def test_gemm_nt_k64_slots(M, N, K, variant):
     """256x160 tiles on 64-deep ring slots (big_mainloop64: 8-row x 128-byte DMA pieces, two multiply steps per slot):
     even / odd numbers of 32-deep steps (K = 96, 160, 800, 2400 end in a half-filled stage whose second step must not be
@@ -614,7 +614,8 @@ def attn_path(request):
 
 
 @pytest.mark.parametrize("B,H,n,dh", [(2, 4, 32, 32), (1, 2, 96, 64), (2, 10, 360, 80), (2, 10, 120, 80),
-                                      (1, 10, 240, 80), (2, 3, 200, 128), (3, 2, 376, 80), (1, 2, 400, 80), (1, 3, 1440, 128)])
+                                      (1, 10, 240, 80), (2, 3, 200, 128), (3, 2, 376, 80), (1, 2, 400, 80), (1, 3, 1440, 128),
+                                      (2, 3, 320, 80), (1, 4, 264, 64)])
 def test_attention_fwd_bwd(attn_path, B, H, n, dh):
     lib = L.lib()
     hid = H * dh
@@ -639,7 +640,7 @@ def test_attention_fwd_bwd(attn_path, B, H, n, dh):
         assert _rel_err(a, r) < 2e-2, "%s rel err %.4g" % (nm, _rel_err(a, r))
 
 
-@pytest.mark.parametrize("variant", [10, 11, 12, 14], ids=["big288x256", "big256x256", "big256x160", "big256x128x2"])
+@pytest.mark.parametrize("variant", [10, 11, 12, 14, 22, 23], ids=["big288x256", "big256x256", "big256x160", "big256x128x2", "m32_256x256", "m32_384x192"])
 def test_attention_heads_epilogue_big_tiles(variant):
     """The per-head scatter epilogue (EPI_HEADS) of the big-tile family: staged through LDS, 16-byte stores,
     column -> (q/k/v, head, dim) by magic division.  Driven through the attention op (identity GEMM)."""

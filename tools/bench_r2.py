@@ -148,6 +148,22 @@ if __name__ == "__main__":
             nt_case(Me, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 12], "enc out-proj")
             nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [1, 10, 11, 14], "enc FFN1")
         nt_case(8192, 8192, 8192, L.EPI_BF16, [1, 7, 11], "8192^3")
+    if what == "m32":  # round 6: 32x32x16 MFMA tiles (v22 = 256x256, v23 = 384x192) vs the 16x16x32 tiles on 64-deep slots (v19 / v18)
+        M = 5760
+        for rep in range(2):
+            nt_case(8192, 8192, 8192, L.EPI_BF16, [19, 22, 23], "8192^3")
+            nt_case(M, 3072, 3072, L.EPI_BF16, [18, 19, 22, 23], "long K")
+            nt_case(M, 3072, 800, L.EPI_BF16, [18, 22, 23], "plain N3072")
+            nt_case(M, 3072, 800, L.EPI_BIAS_GELU, [18, 22, 23], "FFN1+gelu")
+            nt_case(M, 3072, 800, L.EPI_GELU_BWD, [18, 22, 23], "dgrad gelu'")
+            nt_case(M, 2400, 800, L.EPI_BF16, [19, 18, 22, 23], "QKV (plain)")
+        for Me in (3840, 1920):
+            nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [0, 22, 23], "enc FFN1")
+            nt_case(Me, 2400, 800, L.EPI_BF16, [0, 22, 23], "enc QKV")
+    if what == "m32pmc":  # few launches for rocprofv3 --pmc: where does the 32x32x16 loop lose?
+        globals()["ITERS"] = 3
+        nt_case(8192, 8192, 8192, L.EPI_BF16, [19, 22, 23], "8192^3")
+        nt_case(5760, 3072, 3072, L.EPI_BF16, [18, 23], "long K")
     if what == "t192":  # whole-K N = 800 dgrads: 256x160 (v117: 64-deep, no split-K) vs 192x160 (v20), alone on the chip
         for rep in range(2):
             for Me in (5760, 3840, 1920):

@@ -15,7 +15,7 @@ for db in glob.glob(d + "/**/*.db", recursive=True):
     for r in c.execute("select * from counters_collection"):
         k = r[ki] if ki is not None else "?"
         if pat and pat not in k: continue
-        agg[k[:60]][r[ni]].append(r[vi])
+        agg[k[:110]][r[ni]].append(r[vi])
     for k, cs in agg.items():
         print(k)
         for n, v in sorted(cs.items()):
