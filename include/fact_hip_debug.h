@@ -45,7 +45,7 @@ int fact_kprof_kernels(FactHandle* h, int cls, char* buf, int cap);
  *                    wgrad launch (gemm.h TnProblem::csum), 0 = col_tasks_kernel re-reads dpre and the residual gradients
  *   "wgrad_parts", "wgrad_defer", "wgrad_big", "ln_split", "ln_cs", "bwd_splitk", "adam_hold", "ln_fuse", "lite_stream", "keep_pre":
  *                    scheduling / fusion switches of the A/B runs documented in DESIGN.md sections 3 and 6
- *   "tn_loop", "attn_variant", "adam_variant", "big_impl", "tile192", "tile128x160", "sk_sym", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on
+ *   "tn_loop", "attn_variant", "adam_variant", "big_impl", "tile192", "tile128x160", "k64" (bit 0: 256x160 GEMMs, bit 1: 288x256 / 256x256 GEMMs on
  *                    64-deep ring slots; default 3): PROCESS-WIDE kernel selection
  *   "skip":          TIMING-ONLY ablation mask: results are WRONG while it is set */
 int fact_debug_set_option(FactHandle* h, const char* key, int value);
@@ -102,24 +102,18 @@ int fact_probe_mfma(const float* a_regs, const float* b_regs, float* d_regs, voi
 int fact_probe_tr(const float* lds_vals, int n, const int* byte_addrs, float* out, void* stream);
 /* Test knob: route every GEMM through the register-staged generic kernels (process-global). */
 int fact_debug_force_generic_gemm(int on);
-/* Test knob: 1 = use the tiled (streaming) attention kernels even when the LDS-resident ones fit. */
+/* Test knob: 1 = the tiled reference attention kernels (standard online softmax) for every shape. */
 int fact_debug_attn_force_tiled(int on);
-/* Test/bench knob: attention kernel family. 1 (default) = one workgroup per (batch, head) with K/V resident in
- * LDS when they fit, tiled kernels otherwise; 2 = streaming 4-wave kernels (128-row blocks, LDS-DMA ring). */
+/* Test/bench knob: attention kernel family. 5 (default) = streaming forward + lean LDS-resident backward where the head fits
+ * (streaming backward otherwise); 2 = streaming 4-wave kernels everywhere; any other value selects the default. */
 int fact_debug_attn_variant(int v);
 int fact_debug_attn_variant_get(void); /* the current family (tests restore it) */
-/* Bench only: device buffer of u64[B*H][waves][8] that receives per-wave s_memtime stamps of the LDS-resident
- * forward attention kernel (null = off). */
-int fact_debug_attn_timestamps(void* buf);
 /* bench only: `nwg` one-per-CU workgroups that spin for ~`micros` microseconds on `stream` (CU-availability probe) */
 int fact_debug_cu_hog(int nwg, int micros, void* stream);
-/* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 6 / 7 = big-tile 288x256 / 256x256). */
+/* Test/bench knob: NT GEMM kernel choice (0 auto, 1 = 128x128, 10.. = the tile configs of gemm_big.hip, see gemm.hip launch_nt_t). */
 int fact_debug_gemm_splitk_max(int v); /* in-kernel split-K slices of the N = 800 GEMMs (1 = off, default 4) */
-/* 0 = never finish a 2-way in-kernel split-K symmetrically (both slices resident, each runs the epilogue of half the rows;
- * gemm.h GemmParams::sk_sym), 1 = where the caller allows it and the launch fits the chip (default).  Process-wide. */
-int fact_debug_gemm_sk_sym(int v);
 int fact_debug_gemm_tn_cfg(int v); /* grouped wgrad tile: 0 = 160x256, 1 = 160x384 */
-int fact_debug_gemm_big_impl(int v); /* 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel */
+int fact_debug_gemm_big_impl(int v); /* 1 = gemm_big.hip family (default), 2 = without the 256x128 pairs, 0 = 128x128 kernel only */
 int fact_debug_gemm_nt_variant(int v);
 /* Test/bench knob: NT GEMM tile band height (tile order inside an XCD; 1 = row-major, default 8). */
 int fact_debug_gemm_nt_band(int band);

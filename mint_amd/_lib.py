@@ -107,13 +107,11 @@ SIGNATURES = {
     "fact_debug_gemm_big_impl": (_i, [_i]),
     "fact_debug_gemm_tn_cfg": (_i, [_i]),
     "fact_debug_gemm_splitk_max": (_i, [_i]),
-    "fact_debug_gemm_sk_sym": (_i, [_i]),
     "fact_debug_gemm_nt_band": (_i, [_i]),
     "fact_debug_ln_bwd": (_i, [_i, _i]),
     "fact_debug_attn_force_tiled": (_i, [_i]),
     "fact_debug_attn_variant": (_i, [_i]),
     "fact_debug_attn_variant_get": (_i, []),
-    "fact_debug_attn_timestamps": (_i, [_vp]),
     "fact_debug_cu_hog": (_i, [_i, _i, _vp]),
 }
 

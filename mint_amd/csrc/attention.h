@@ -31,15 +31,12 @@ struct AttnParams {
                       // those rows only; backward treats dO rows >= nq as zero (the LDS-resident kernels skip the work,
                       // the other families rely on the caller having zeroed those dO rows)
   int qblocks;        // filled by the launcher: 128-query blocks per head of the streaming forward's 1-D grid
-  unsigned long long* ts;  // bench only: per-wave s_memtime stamps of the resident forward kernel (null = off)
 };
 
 int launch_attn_fwd(const AttnParams& p, hipStream_t s);
 int launch_attn_bwd(const AttnParams& p, hipStream_t s);  // prep + dQ + dKdV
-// kernel families (forward + backward): 1 = LDS-resident (tiled when the head does not fit), 2 = streaming 4-wave kernels,
-// 3 = streaming forward + resident backward, 4 = the reverse, 5 = streaming forward + lean resident backward (round 4),
-// 6 = resident forward + lean backward, 7 / 8 = 5 / 6 with packed fp32 softmax arithmetic in the backward
+// kernel families (round 6: pruned): 5 (default) = streaming forward + lean LDS-resident backward where the head fits, streaming
+// backward otherwise; 2 = streaming kernels everywhere; any other value selects 5.  attn_set_force_tiled(1) = the tiled reference path.
 void attn_set_variant(int v);
 int attn_get_variant();
 void attn_set_force_tiled(int on);
-void attn_set_ts(unsigned long long* buf);  // bench only: timestamp buffer, [B*H][waves][8]  // bench only: timing ablation bits of the streaming forward kernel  // test knob: 1 = tiled (streaming) kernels even when the LDS-resident ones fit

@@ -461,406 +461,10 @@ DEVINL bf16x8 res_frag_row(const unsigned char* img, int row, int kd, int lane) 
   const int c = kd * 4 + (lane >> 4);
   return *reinterpret_cast<const bf16x8*>(img + r * (DHP * 2) + ((c ^ res_g(r)) << 4));
 }
-// token-contracting fragment [16 dims of tile dt][32 tokens from tok0] from an img96 (slot convention
-// as frag_tr above)
-template <int DHP>
-DEVINL bf16x8 res_frag_tr96(const unsigned char* img, int tok0, int dt, int lane) {
-  const int g = lane >> 4, s = lane & 15;
-  const int r = tok0 + g * 4 + (s >> 2);
-  const int off = r * (DHP * 2) + (((dt * 2 + ((s & 3) >> 1)) ^ res_g(r)) << 4) + (s & 1) * 8;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off + 16 * DHP * 2));
-  return cat4(lo, hi);
-}
-// same from an un-swizzled img80 ([rows][DH])
-template <int DH>
-DEVINL bf16x8 res_frag_tr80(const unsigned char* img, int tok0, int dt, int lane) {
-  const int g = lane >> 4, s = lane & 15;
-  const int off = (tok0 + g * 4 + (s >> 2)) * (DH * 2) + (dt * 16 + (s & 3) * 4) * 2;
-  const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off));
-  const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + off + 16 * DH * 2));
-  return cat4(lo, hi);
-}
 
-template <int DH>
-__global__ __launch_bounds__(768) void attn_fwd_res_kernel(const AttnParams p) {
-  using G = Geo<DH>;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, g = lane >> 4;
-  const int bh = blockIdx.x;
-  unsigned long long* ts = p.ts ? p.ts + ((size_t)bh * nw + wave) * 8 : nullptr;
-  auto stamp = [&](int i) {
-    if (ts && lane == 0) ts[i] = __builtin_readcyclecounter();
-  };
-  stamp(0);
-  const int rows = (p.n + 31) & ~31;
-  unsigned char* Kimg = smem;
-  unsigned char* Vimg = smem + (((size_t)rows * G::DHP * 2 + 1023) & ~(size_t)1023);
-  const size_t row_base = (size_t)bh * p.NP * G::DHP;
-  res_load<G::DHP, G::DHP / 8, true>(Kimg, p.krow + row_base, rows, wave, nw, lane);
-  res_load<G::DHP, DH / 8, false>(Vimg, p.vrow + row_base, rows, wave, nw, lane);
-
-  const int q0 = wave * 32;
-  bf16x8 Qf[2][G::KD];
-#pragma unroll
-  for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-    for (int kd = 0; kd < G::KD; ++kd)
-      Qf[qs][kd] = *reinterpret_cast<const bf16x8*>(
-          p.qrow + row_base + (size_t)(q0 + qs * 16 + (lane & 15)) * G::DHP + kd * 32 + g * 8);
-  f32x4 O[2][G::ND];
-  float m[2], l[2];
-#pragma unroll
-  for (int qs = 0; qs < 2; ++qs) {
-    m[qs] = -INFINITY;
-    l[qs] = 0.f;
-#pragma unroll
-    for (int dt = 0; dt < G::ND; ++dt) O[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  stamp(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  stamp(2);
-  __syncthreads();
-  stamp(3);
-  if (p.nq > 0 && q0 >= p.nq) return;  // supervised-rows shortcut: no barrier follows, the wave can leave
-
-  const float sc = p.scale * LOG2E;
-  const int nkt = rows >> 5;
-  for (int kt = 0; kt < nkt; ++kt) {
-    if (kt == 1) stamp(4);
-    if (kt == nkt / 2) stamp(5);
-    f32x4 s[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int kd = 0; kd < G::KD; ++kd) {
-        const bf16x8 kf = res_frag_row<G::DHP>(Kimg, kt * 32 + ks * 16, kd, lane);
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) s[ks][qs] = mfma16(kf, Qf[qs][kd], s[ks][qs]);
-      }
-    // padded keys only exist in the last tile (wave-uniform branch); the softmax scale is folded
-    // into the exponent below: exp2(s*sc - m) with m tracked in the scaled domain
-    if (kt == nkt - 1 && (p.n & 31)) {
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool valid = (kt * 32 + ks * 16 + g * 4 + r) < p.n;
-#pragma unroll
-          for (int qs = 0; qs < 2; ++qs) s[ks][qs][r] = valid ? s[ks][qs][r] : -INFINITY;
-        }
-    }
-    bf16x8 pb[2];
-#pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-      float mx = fmaxf(fmaxf(fmaxf(s[0][qs][0], s[0][qs][1]), fmaxf(s[0][qs][2], s[0][qs][3])),
-                       fmaxf(fmaxf(s[1][qs][0], s[1][qs][1]), fmaxf(s[1][qs][2], s[1][qs][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m[qs], mx * sc);  // sc > 0: max commutes with the scale
-      f32x4 p0, p1;
-      float ls = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p0[r] = __builtin_amdgcn_exp2f(fmaf(s[0][qs][r], sc, -mn));
-        p1[r] = __builtin_amdgcn_exp2f(fmaf(s[1][qs][r], sc, -mn));
-        ls += p0[r] + p1[r];
-      }
-      if (__any(mn > m[qs])) {  // exact online-softmax rescale, skipped (wave-uniformly) when no row max grew
-        const float alpha = __builtin_amdgcn_exp2f(m[qs] - mn);
-        l[qs] *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < G::ND; ++dt) {
-          O[qs][dt][0] *= alpha; O[qs][dt][1] *= alpha; O[qs][dt][2] *= alpha; O[qs][dt][3] *= alpha;
-        }
-      }
-      l[qs] += ls;
-      m[qs] = mn;
-      pb[qs] = pack8(p0, p1);
-    }
-#pragma unroll
-    for (int dt = 0; dt < G::ND; ++dt) {
-      const bf16x8 vf = res_frag_tr80<DH>(Vimg, kt * 32, dt, lane);
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) O[qs][dt] = mfma16(vf, pb[qs], O[qs][dt]);
-    }
-  }
-  stamp(6);
-  const int b = bh / p.H, h = bh - b * p.H;
-#pragma unroll
-  for (int qs = 0; qs < 2; ++qs) {
-    float lt = l[qs];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
-    const float inv = 1.0f / lt;
-    const int t = q0 + qs * 16 + (lane & 15);
-    if (g == 0 && t < p.NP) p.lse2[(size_t)bh * p.NP + t] = m[qs] + __log2f(lt);
-    if (t < p.n) {
-      bf16_t* orow = p.out + ((size_t)b * p.n + t) * p.ldo + h * DH + g * 4;
-#pragma unroll
-      for (int dt = 0; dt < G::ND; ++dt) {
-        bf16x4 o = {(bf16_t)(O[qs][dt][0] * inv), (bf16_t)(O[qs][dt][1] * inv),
-                    (bf16_t)(O[qs][dt][2] * inv), (bf16_t)(O[qs][dt][3] * inv)};
-        *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
-      }
-    }
-  }
-  if (ts) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    stamp(7);
-  }
-}
-
-template <int DH>
-__global__ __launch_bounds__(768) void attn_bwd_dq_res_kernel(const AttnParams p) {
-  using G = Geo<DH>;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, g = lane >> 4;
-  const int bh = blockIdx.x;
-  const int rows = (p.n + 31) & ~31;
-  unsigned char* Kimg = smem;
-  unsigned char* Vimg = smem + (((size_t)rows * G::DHP * 2 + 1023) & ~(size_t)1023);
-  const size_t row_base = (size_t)bh * p.NP * G::DHP;
-  res_load<G::DHP, G::DHP / 8, true>(Kimg, p.krow + row_base, rows, wave, nw, lane);
-  res_load<G::DHP, G::DHP / 8, true>(Vimg, p.vrow + row_base, rows, wave, nw, lane);
-
-  const int q0 = wave * 32;
-  const int b = bh / p.H, h = bh - b * p.H;
-  if (p.nq > 0 && q0 >= p.nq) {
-    // supervised-rows shortcut: dO is zero on these query rows, so is dQ (the QKV dgrad reads every row)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-      const int t = q0 + qs * 16 + (lane & 15);
-      if (t < p.n) {
-        bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * p.ldq + h * DH + g * 4;
-#pragma unroll
-        for (int dt = 0; dt < G::ND; ++dt) *reinterpret_cast<bf16x4*>(orow + dt * 16) = bf16x4{};
-      }
-    }
-    return;
-  }
-  bf16x8 Qf[2][G::KD], dOf[2][G::KD];
-  float L2q[2], Dq[2];
-#pragma unroll
-  for (int qs = 0; qs < 2; ++qs) {
-    const int q = q0 + qs * 16 + (lane & 15);
-    // D[q] = rowsum(dO o O) is computed here (no separate pass over dO and O): this lane holds 8 head
-    // columns of dO per 32-column slab, the 4 lanes of a row (g = 0..3) cover the slab
-    float part = 0.f;
-#pragma unroll
-    for (int kd = 0; kd < G::KD; ++kd) {
-      const size_t off = row_base + (size_t)q * G::DHP + kd * 32 + g * 8;
-      Qf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.qrow + off);
-      dOf[qs][kd] = *reinterpret_cast<const bf16x8*>(p.dorow + off);
-      const int d0 = kd * 32 + g * 8;
-      if (q < p.n && d0 < DH) {
-        const bf16x8 ov = *reinterpret_cast<const bf16x8*>(p.o + ((size_t)b * p.n + q) * p.ldo + h * DH + d0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) part += (float)dOf[qs][kd][j] * (float)ov[j];
-      }
-    }
-    part += __shfl_xor(part, 16);
-    part += __shfl_xor(part, 32);
-    L2q[qs] = p.lse2[(size_t)bh * p.NP + q];
-    Dq[qs] = part;
-    if (g == 0) p.dsum[(size_t)bh * p.NP + q] = part;  // for the dK/dV kernel (0 on padded query rows)
-  }
-  f32x4 dQ[2][G::ND];
-#pragma unroll
-  for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-    for (int dt = 0; dt < G::ND; ++dt) dQ[qs][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const float sc = p.scale * LOG2E;
-  const int nkt = rows >> 5;
-  for (int kt = 0; kt < nkt; ++kt) {
-    f32x4 s[2][2], dp[2][2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
-        s[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dp[ks][qs] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int kd = 0; kd < G::KD; ++kd) {
-        const bf16x8 kf = res_frag_row<G::DHP>(Kimg, kt * 32 + ks * 16, kd, lane);
-        const bf16x8 vf = res_frag_row<G::DHP>(Vimg, kt * 32 + ks * 16, kd, lane);
-#pragma unroll
-        for (int qs = 0; qs < 2; ++qs) {
-          s[ks][qs] = mfma16(kf, Qf[qs][kd], s[ks][qs]);
-          dp[ks][qs] = mfma16(vf, dOf[qs][kd], dp[ks][qs]);
-        }
-      }
-    bf16x8 dsb[2];
-#pragma unroll
-    for (int qs = 0; qs < 2; ++qs) {
-      f32x4 d0, d1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool v0 = (kt * 32 + g * 4 + r) < p.n;
-        const bool v1 = (kt * 32 + 16 + g * 4 + r) < p.n;
-        const float p0 = v0 ? __builtin_amdgcn_exp2f(fmaf(s[0][qs][r], sc, -L2q[qs])) : 0.f;
-        const float p1 = v1 ? __builtin_amdgcn_exp2f(fmaf(s[1][qs][r], sc, -L2q[qs])) : 0.f;
-        d0[r] = p0 * (dp[0][qs][r] - Dq[qs]);
-        d1[r] = p1 * (dp[1][qs][r] - Dq[qs]);
-      }
-      dsb[qs] = pack8(d0, d1);
-    }
-#pragma unroll
-    for (int dt = 0; dt < G::ND; ++dt) {
-      const bf16x8 ktf = res_frag_tr96<G::DHP>(Kimg, kt * 32, dt, lane);
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) dQ[qs][dt] = mfma16(ktf, dsb[qs], dQ[qs][dt]);
-    }
-  }
-#pragma unroll
-  for (int qs = 0; qs < 2; ++qs) {
-    const int t = q0 + qs * 16 + (lane & 15);
-    if (t < p.n) {
-      bf16_t* orow = p.dqkv + ((size_t)b * p.n + t) * p.ldq + h * DH + g * 4;
-#pragma unroll
-      for (int dt = 0; dt < G::ND; ++dt) {
-        bf16x4 o = {(bf16_t)(dQ[qs][dt][0] * p.scale), (bf16_t)(dQ[qs][dt][1] * p.scale),
-                    (bf16_t)(dQ[qs][dt][2] * p.scale), (bf16_t)(dQ[qs][dt][3] * p.scale)};
-        *reinterpret_cast<bf16x4*>(orow + dt * 16) = o;
-      }
-    }
-  }
-}
-
-// dK/dV: 8 waves (2 per SIMD, 256-VGPR budget: K/V fragments + both accumulators stay in registers);
-// the 32-key slots of the head are dealt round-robin, so with 12 slots every SIMD gets 3.
-template <int DH>
-__global__ __launch_bounds__(512) void attn_bwd_dkdv_res_kernel(const AttnParams p) {
-  using G = Geo<DH>;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, g = lane >> 4;
-  const int bh = blockIdx.x;
-  const int rows = (p.n + 31) & ~31;
-  const size_t img_bytes = ((size_t)rows * G::DHP * 2 + 1023) & ~(size_t)1023;
-  unsigned char* Qimg = smem;
-  unsigned char* dOimg = smem + img_bytes;
-  float* L2s = reinterpret_cast<float*>(smem + 2 * img_bytes);
-  float* Dss = L2s + rows;
-  const size_t row_base = (size_t)bh * p.NP * G::DHP;
-  res_load<G::DHP, G::DHP / 8, true>(Qimg, p.qrow + row_base, rows, wave, nw, lane);
-  res_load<G::DHP, G::DHP / 8, true>(dOimg, p.dorow + row_base, rows, wave, nw, lane);
-  for (int i = tid; i < rows; i += blockDim.x) {
-    L2s[i] = p.lse2[(size_t)bh * p.NP + i];
-    Dss[i] = p.dsum[(size_t)bh * p.NP + i];
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  const float sc = p.scale * LOG2E;
-  const int nqt = rows >> 5;
-  const int nqv = (p.nq > 0 && p.nq < p.n) ? p.nq : p.n;  // valid query rows (supervised-rows shortcut: dO rows >= nq are zero)
-  const int nqt_eff = (nqv + 31) >> 5;
-  const int b = bh / p.H, h = bh - b * p.H;
-  for (int slot = wave; slot < nqt; slot += nw) {
-    const int key0 = slot * 32;
-    bf16x8 Kf[2][G::KD], Vf[2][G::KD];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int kd = 0; kd < G::KD; ++kd) {
-        const size_t off = row_base + (size_t)(key0 + ks * 16 + (lane & 15)) * G::DHP + kd * 32 + g * 8;
-        Kf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.krow + off);
-        Vf[ks][kd] = *reinterpret_cast<const bf16x8*>(p.vrow + off);
-      }
-    f32x4 dK[2][G::ND], dV[2][G::ND];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int dt = 0; dt < G::ND; ++dt) {
-        dK[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dV[ks][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    bool kvalid[2];
-    kvalid[0] = (key0 + (lane & 15)) < p.n;
-    kvalid[1] = (key0 + 16 + (lane & 15)) < p.n;
-    for (int qt = 0; qt < nqt_eff; ++qt) {
-      f32x4 s[2][2], dp[2][2];  // [qsub][ksub]
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          s[qs][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
-          dp[qs][ks] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-        for (int kd = 0; kd < G::KD; ++kd) {
-          const bf16x8 qf = res_frag_row<G::DHP>(Qimg, qt * 32 + qs * 16, kd, lane);
-          const bf16x8 df = res_frag_row<G::DHP>(dOimg, qt * 32 + qs * 16, kd, lane);
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-            s[qs][ks] = mfma16(qf, Kf[ks][kd], s[qs][ks]);
-            dp[qs][ks] = mfma16(df, Vf[ks][kd], dp[qs][ks]);
-          }
-        }
-      const f32x4 l2a = *reinterpret_cast<const f32x4*>(&L2s[qt * 32 + g * 4]);
-      const f32x4 l2b = *reinterpret_cast<const f32x4*>(&L2s[qt * 32 + 16 + g * 4]);
-      const f32x4 dda = *reinterpret_cast<const f32x4*>(&Dss[qt * 32 + g * 4]);
-      const f32x4 ddb = *reinterpret_cast<const f32x4*>(&Dss[qt * 32 + 16 + g * 4]);
-      bf16x8 pb[2], dsb[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        f32x4 p0, p1, d0, d1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // padded keys AND padded query rows are masked (shared dO scratch: see the tiled kernel)
-          const bool qv0 = (qt * 32 + g * 4 + r) < nqv, qv1 = (qt * 32 + 16 + g * 4 + r) < nqv;
-          p0[r] = (kvalid[ks] && qv0) ? __builtin_amdgcn_exp2f(fmaf(s[0][ks][r], sc, -l2a[r])) : 0.f;
-          p1[r] = (kvalid[ks] && qv1) ? __builtin_amdgcn_exp2f(fmaf(s[1][ks][r], sc, -l2b[r])) : 0.f;
-          d0[r] = p0[r] * (dp[0][ks][r] - dda[r]);
-          d1[r] = p1[r] * (dp[1][ks][r] - ddb[r]);
-        }
-        pb[ks] = pack8(p0, p1);
-        dsb[ks] = pack8(d0, d1);
-      }
-#pragma unroll
-      for (int dt = 0; dt < G::ND; ++dt) {
-        const bf16x8 dof = res_frag_tr96<G::DHP>(dOimg, qt * 32, dt, lane);
-        const bf16x8 qtf = res_frag_tr96<G::DHP>(Qimg, qt * 32, dt, lane);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          dV[ks][dt] = mfma16(dof, pb[ks], dV[ks][dt]);
-          dK[ks][dt] = mfma16(qtf, dsb[ks], dK[ks][dt]);
-        }
-      }
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int t = key0 + ks * 16 + (lane & 15);
-      if (t < p.n) {
-        bf16_t* krow_o = p.dqkv + ((size_t)b * p.n + t) * p.ldq + p.hid + h * DH + g * 4;
-        bf16_t* vrow_o = krow_o + p.hid;
-#pragma unroll
-        for (int dt = 0; dt < G::ND; ++dt) {
-          bf16x4 ok = {(bf16_t)(dK[ks][dt][0] * p.scale), (bf16_t)(dK[ks][dt][1] * p.scale),
-                       (bf16_t)(dK[ks][dt][2] * p.scale), (bf16_t)(dK[ks][dt][3] * p.scale)};
-          bf16x4 ov = {(bf16_t)dV[ks][dt][0], (bf16_t)dV[ks][dt][1], (bf16_t)dV[ks][dt][2],
-                       (bf16_t)dV[ks][dt][3]};
-          *reinterpret_cast<bf16x4*>(krow_o + dt * 16) = ok;
-          *reinterpret_cast<bf16x4*>(vrow_o + dt * 16) = ov;
-        }
-      }
-    }
-  }
-}
+// (Round 6: the round-2/3 LDS-resident kernels - attn_fwd_res_kernel, attn_bwd_dq_res_kernel, attn_bwd_dkdv_res_kernel - were
+// removed from the library; the lean resident backward below is their successor, the streaming forward the default forward, the
+// tiled kernels the forced reference path.  git history: round 5.)
 
 // =============================================================================================
 // Streaming family (round 2).  The LDS-resident kernels above put one 8..12-wave workgroup per (batch, head)
@@ -1827,17 +1431,18 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv_r2_kernel(const AttnParams 
   }
 }
 
-// 1 = LDS-resident kernels when the head fits (tiled otherwise), 2 = streaming family, 3 = streaming forward + resident
-// backward (default, round 3: the forward runs alone on the chip, where the 480-workgroup streaming kernel is 4 us
-// shorter; the backward kernels run beside the 95-workgroup wgrad launches, where the 160-workgroup resident ones leave
-// it the CUs - same-box A/B of the step: 7.97-7.99 / 7.94-7.95 / 7.87-7.90 / 8.00-8.01 ms for 1 / 2 / 3 / 4), 4 = the reverse,
-// 5 (default, round 4) = streaming forward + LEAN resident backward (kernels above: dQ 30.0 -> 26.9 us, dK/dV 32.9 -> 26.7 us
-// alone, 38.2 -> 32.5 us per launch in the step, step 7.64 -> 7.58 ms same box), 6 = resident forward + lean backward,
-// 7 / 8 = 5 / 6 with packed fp32 softmax arithmetic (28.1 / 27.8 us: v_pk_* issue half as often but run twice as long)
+// Kernel families (round 6: pruned to the default and one reference path per op, round-5 review item 7):
+//   5 (default) = streaming forward (480 workgroups, runs alone on the chip) + LEAN LDS-resident backward where the head fits
+//                 (n <= 384, head dim <= 96: runs beside the 95-workgroup wgrad launches and leaves them the CUs), streaming
+//                 backward otherwise (the scaled configuration: n = 1440, head dim 128);
+//   2           = streaming kernels everywhere (A/B knob);
+//   force_tiled = the tiled kernels of round 1 (standard online softmax, no lazy maximum): the forced reference path.
+// Rounds 2-5 also carried the round-2/3 resident family (variants 1 / 3 / 4 / 6) and packed-fp32 forms of the lean backward
+// (7 / 8: slower, profiles/r04_ab_attn_variants.txt); any other value now selects the default.
 int g_attn_variant = 5;
 int g_attn_force_tiled = 0;  // test knob: 1 = always use the tiled (streaming) kernels
 
-// LDS bytes of the resident kernels for n tokens; 0 = does not fit -> tiled kernels
+// LDS bytes of the lean resident backward kernels for n tokens (1 = dQ, 2 = dK/dV); 0 = does not fit -> streaming kernels
 template <int DH>
 size_t res_lds_bytes(int n, int which /*0 fwd, 1 dq, 2 dkdv*/) {
   using G = Geo<DH>;
@@ -1884,20 +1489,16 @@ int allow_lds_bytes(K kernel, bool* done, size_t bytes) {
   return 0;
 }
 
-// does launch_attn_bwd run the LDS-resident kernels (old or lean) for n tokens?  They honour AttnParams::nq; the
-// streaming backward (variants 2 / 4, or whatever the resident kernels cannot hold) does not.
+// does launch_attn_bwd run the lean LDS-resident kernels for n tokens?  They honour AttnParams::nq; the streaming backward
+// (variant 2, or whatever the resident kernels cannot hold) does not.
 template <int DH>
 bool bwd_is_resident(int n) {
-  return g_attn_variant != 2 && g_attn_variant != 4 && !g_attn_force_tiled && res_lds_bytes<DH>(n, 1) &&
-         res_lds_bytes<DH>(n, 2);
+  return g_attn_variant != 2 && !g_attn_force_tiled && res_lds_bytes<DH>(n, 1) && res_lds_bytes<DH>(n, 2);
 }
 
 template <int DH>
 int fwd_t(const AttnParams& p, hipStream_t s) {
-  // streaming kernel: the default forward; also whatever the resident kernels cannot hold (head dims above 96, n > 384)
-  if ((g_attn_variant == 2 || g_attn_variant == 3 || g_attn_variant == 5 || g_attn_variant == 7 ||
-       !res_lds_bytes<DH>(p.n, 0)) &&
-      !g_attn_force_tiled) {
+  if (!g_attn_force_tiled) {  // streaming kernel: the forward of every shape
     constexpr size_t lds = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG;
     static bool attr = false;
     if (int rc = allow_lds_bytes(attn_fwd_st_kernel<DH>, &attr, lds)) return rc;
@@ -1910,89 +1511,49 @@ int fwd_t(const AttnParams& p, hipStream_t s) {
     FACT_LAUNCH(attn_fwd_st_kernel<DH>, dim3(q.qblocks * q.B * q.H), dim3(256), lds, s, q);
     return 0;
   }
-  const size_t lds = res_lds_bytes<DH>(p.n, 0);
-  if constexpr (DH <= 96) if (lds) {
-    static bool attr = false;
-    if (int rc = allow_big_lds(attn_fwd_res_kernel<DH>, &attr)) return rc;
-    const int nw = ((p.n + 31) & ~31) / 32;
-    AttnParams q = p;
-    if (!bwd_is_resident<DH>(p.n)) q.nq = 0;  // variant 4: the streaming backward reads every row's log-sum-exp
-    FACT_LAUNCH(attn_fwd_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds, s, q);
-    return 0;
-  }
-  dim3 grid((p.n + 127) / 128, p.B * p.H);
+  dim3 grid((p.n + 127) / 128, p.B * p.H);  // forced reference path
   FACT_LAUNCH(attn_fwd_kernel<DH>, grid, dim3(256), 0, s, p);
   return 0;
 }
 template <int DH>
 int bwd_t(const AttnParams& p, hipStream_t s) {
-  if (!bwd_is_resident<DH>(p.n) && !g_attn_force_tiled) {
-    constexpr size_t lds1 = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG, lds2 = (size_t)SG<DH>::NSLOT * (2 * SG<DH>::IMG + 256);
-    static bool attr1 = false, attr2 = false;
-    if (int rc = allow_lds_bytes(attn_bwd_dq_st_kernel<DH>, &attr1, lds1)) return rc;
-    if (int rc = allow_lds_bytes(attn_bwd_dkdv_st_kernel<DH>, &attr2, lds2)) return rc;
-    const dim3 grid((p.n + 127) / 128, p.B * p.H);
-    FACT_LAUNCH(attn_bwd_dq_st_kernel<DH>, grid, dim3(256), lds1, s, p);
-    FACT_LAUNCH(attn_bwd_dkdv_st_kernel<DH>, grid, dim3(256), lds2, s, p);
-    return 0;
-  }
-  const int total = p.B * p.H * p.NP;
-  const size_t lds1 = res_lds_bytes<DH>(p.n, 1), lds2 = res_lds_bytes<DH>(p.n, 2);
-  // the LDS-resident dQ kernel computes D = rowsum(dO o O) itself; only the tiled path needs the pass
-  if (!lds1) FACT_LAUNCH(attn_bwd_prep_kernel<DH>, dim3((total + 255) / 256), dim3(256), 0, s, p);
-  const int nw = ((p.n + 31) & ~31) / 32;
-  dim3 grid((p.n + 127) / 128, p.B * p.H);
-  if constexpr (DH <= 96) {
-    const bool r2 = g_attn_variant >= 5, pk = g_attn_variant >= 7;
-    if (lds1 && r2 && pk) {
-      static bool attr = false;
-      if (int rc = allow_big_lds(attn_bwd_dq_r2_kernel<DH, 1>, &attr)) return rc;
-      FACT_LAUNCH((attn_bwd_dq_r2_kernel<DH, 1>), dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
-    } else if (lds1 && r2) {
-      static bool attr = false;
-      if (int rc = allow_big_lds(attn_bwd_dq_r2_kernel<DH, 0>, &attr)) return rc;
-      FACT_LAUNCH((attn_bwd_dq_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
-    } else if (lds1) {
-      static bool attr = false;
-      if (int rc = allow_big_lds(attn_bwd_dq_res_kernel<DH>, &attr)) return rc;
-      FACT_LAUNCH(attn_bwd_dq_res_kernel<DH>, dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
-    } else {
-      FACT_LAUNCH(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
-    }
-    if (lds2 && r2 && pk) {
-      static bool attr = false;
-      if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 1>, &attr)) return rc;
-      FACT_LAUNCH((attn_bwd_dkdv_r2_kernel<DH, 1>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
-    } else if (lds2 && r2) {
-      static bool attr = false;
-      if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 0>, &attr)) return rc;
-      FACT_LAUNCH((attn_bwd_dkdv_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
-    } else if (lds2) {
-      static bool attr = false;
-      if (int rc = allow_big_lds(attn_bwd_dkdv_res_kernel<DH>, &attr)) return rc;
-      FACT_LAUNCH(attn_bwd_dkdv_res_kernel<DH>, dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
-    } else {
-      FACT_LAUNCH(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
-    }
-  } else {
+  const dim3 grid((p.n + 127) / 128, p.B * p.H);
+  if (g_attn_force_tiled) {  // forced reference path: D = rowsum(dO o O) pass, then the tiled dQ and dK/dV kernels
+    const int total = p.B * p.H * p.NP;
+    FACT_LAUNCH(attn_bwd_prep_kernel<DH>, dim3((total + 255) / 256), dim3(256), 0, s, p);
     FACT_LAUNCH(attn_bwd_dq_kernel<DH>, grid, dim3(256), 0, s, p);
     FACT_LAUNCH(attn_bwd_dkdv_kernel<DH>, grid, dim3(256), 0, s, p);
+    return 0;
   }
+  if constexpr (DH <= 96) {
+    if (bwd_is_resident<DH>(p.n)) {  // lean LDS-resident backward (the dQ kernel computes D itself)
+      const size_t lds1 = res_lds_bytes<DH>(p.n, 1), lds2 = res_lds_bytes<DH>(p.n, 2);
+      const int nw = ((p.n + 31) & ~31) / 32;
+      static bool attr1 = false, attr2 = false;
+      if (int rc = allow_big_lds(attn_bwd_dq_r2_kernel<DH, 0>, &attr1)) return rc;
+      if (int rc = allow_big_lds(attn_bwd_dkdv_r2_kernel<DH, 0>, &attr2)) return rc;
+      FACT_LAUNCH((attn_bwd_dq_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3(nw * 64), lds1, s, p);
+      FACT_LAUNCH((attn_bwd_dkdv_r2_kernel<DH, 0>), dim3(p.B * p.H), dim3((nw < 8 ? nw : 8) * 64), lds2, s, p);
+      return 0;
+    }
+  }
+  constexpr size_t lds1 = (size_t)SG<DH>::NSLOT * 2 * SG<DH>::IMG, lds2 = (size_t)SG<DH>::NSLOT * (2 * SG<DH>::IMG + 256);
+  static bool attr1 = false, attr2 = false;
+  if (int rc = allow_lds_bytes(attn_bwd_dq_st_kernel<DH>, &attr1, lds1)) return rc;
+  if (int rc = allow_lds_bytes(attn_bwd_dkdv_st_kernel<DH>, &attr2, lds2)) return rc;
+  FACT_LAUNCH(attn_bwd_dq_st_kernel<DH>, grid, dim3(256), lds1, s, p);
+  FACT_LAUNCH(attn_bwd_dkdv_st_kernel<DH>, grid, dim3(256), lds2, s, p);
   return 0;
 }
 
 }  // namespace
 
 void attn_set_force_tiled(int on) { g_attn_force_tiled = on; }
-void attn_set_variant(int v) { g_attn_variant = v; }
+void attn_set_variant(int v) { g_attn_variant = (v == 2) ? 2 : 5; }
 int attn_get_variant() { return g_attn_variant; }
 
-unsigned long long* g_attn_ts = nullptr;
-void attn_set_ts(unsigned long long* buf) { g_attn_ts = buf; }
-
 int launch_attn_fwd(const AttnParams& p_in, hipStream_t s) {
-  AttnParams p = p_in;
-  p.ts = g_attn_ts;
+  const AttnParams& p = p_in;
   int rc = check(p);
   if (rc) return rc;
   switch (p.dh) {

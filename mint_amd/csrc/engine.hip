@@ -1016,11 +1016,6 @@ int layer_forward(FactHandle* h, Stack& st, int l, int B, hipStream_t s) {
     g.ep.out0 = a.x_out; g.ep.ldo0 = d; g.ep.bias = P(h, p.b2); g.ep.resid = a.x_mid; g.ep.ldr = d;
     with_ws(h, g, s);
     with_skinny_fwd(h, g, s);
-    // symmetric split-K finish (gemm.h GemmParams::sk_sym; OPT-IN since round 6 - debug option sk_sym = 1, gemm.hip g_sk_sym):
-    // within this handle the cross-modal stack's forward is the only work in flight (the two encoder streams were joined
-    // before it, model_forward_hidden), so its 2 x 115 workgroups are co-resident; what the engine cannot see - another
-    // handle, process or RCCL kernel on the same GPU - is why the spinning finish is not a default
-    g.sk_sym = (&st == &h->cross) ? 1 : 0;
     if (l + 1 < st.L && st.la[l + 1].x_in == a.x_out) {  // LayerNorm 1 of the next layer of this stack
       LayerP& pn = st.lp[l + 1];
       LayerA& an = st.la[l + 1];
@@ -1842,10 +1837,6 @@ int fact_debug_set_option(FactHandle* h, const char* key, int value) {
     gemm_set_k64(value);
     return 0;
   }
-  if (!strcmp(key, "sk_sym")) {  // process-wide: 0 = never the symmetric 2-way split-K finish of the cross-modal FFN2 GEMM
-    gemm_set_sk_sym(value);
-    return 0;
-  }
   if (!strcmp(key, "tile128x160")) {  // process-wide: short-K N = 800 GEMMs on 128x160 tiles (225 workgroups at M = 5760)
     gemm_set_tile128x160(value);
     return 0;
@@ -1866,7 +1857,7 @@ int fact_debug_set_option(FactHandle* h, const char* key, int value) {
     h->adam_hold = value;
     return 0;
   }
-  if (!strcmp(key, "big_impl")) {  // process-wide (gemm_set_big_impl): 0 round-1 big kernel, 1 default, 2 no 256x128
+  if (!strcmp(key, "big_impl")) {  // process-wide (gemm_set_big_impl): 1 default, 2 no 256x128 pairs, 0 = 128x128 kernel only
     gemm_set_big_impl(value);
     return 0;
   }
@@ -2331,7 +2322,6 @@ int fact_op_gemm_nt(int epi, const void* A, int lda, const void* B, int ldb, int
     }
     g.sk_slab = slab;
     g.sk_cnt = cnt;
-    g.sk_sym = 1;  // the op runs alone on the device (tests, benches): symmetric 2-way finish where the dispatcher allows it
   }
   CHK(launch_gemm_nt(epi, g, (hipStream_t)stream));
   return 0;
@@ -2431,10 +2421,6 @@ int fact_debug_gemm_tn_cfg(int v) {  // low byte: main loop (0 staggered, 1 / 2 
 }
 int fact_debug_gemm_splitk_max(int v) {
   gemm_set_splitk_max(v);
-  return 0;
-}
-int fact_debug_gemm_sk_sym(int v) {
-  gemm_set_sk_sym(v);
   return 0;
 }
 int fact_debug_gemm_big_impl(int v) {
@@ -2618,10 +2604,6 @@ int fact_debug_cu_hog(int nwg, int micros, void* stream) {
   if (n <= 0) return 0;
   FACT_LAUNCH(cu_hog_kernel, dim3(n), dim3(256), (mode & 1) ? 1024 : 96 * 1024, (hipStream_t)stream,
                      (long long)micros * 100, sink, mode);  // wall_clock64() ticks at 100 MHz
-  return 0;
-}
-int fact_debug_attn_timestamps(void* buf) {
-  attn_set_ts((unsigned long long*)buf);
   return 0;
 }
 int fact_debug_attn_variant(int v) {

@@ -65,11 +65,6 @@ struct GemmParams {
   // stream: launches that may run concurrently must not share it.
   float* sk_slab;
   unsigned* sk_cnt;
-  // 1: a 2-way in-kernel split-K may finish SYMMETRICALLY - both slices of a tile stay resident, each waits for the other's
-  // partial and runs the epilogue of half the tile's rows (gemm_big.hip; fp32 epilogues).  The caller asserts that nothing
-  // else can keep the launch's workgroups from being co-resident: this GEMM's stream is the only one with spinning
-  // workgroups in flight (the dispatcher additionally requires tiles * 2 <= CUs).
-  int sk_sym;
   // Skinny-M path (optional): a ZERO-FILLED fp32 accumulator of >= M * round4(N) floats.  When present and
   // M <= 512 the GEMM runs as split-K 128x128 tiles with fp32 atomics into it (a 320-row GEMM has only 21
   // N = 800 tiles: the K loop is cut so that ~256 workgroups share it), followed by one element-wise kernel that
@@ -146,11 +141,10 @@ bool gemm_nt_takes_skinny(int epi, const GemmParams& p);
 // Launchers. Return 0 on success, negative on invalid arguments.
 int launch_gemm_nt(int epi, const GemmParams& p, hipStream_t stream);
 int launch_gemm_tn(int epi, const GemmParams& p, hipStream_t stream);
-void gemm_set_nt_variant(int v);  // 0 auto, 1 = 128x128, 6 / 7 = round-1 big tile, 10 / 11 / 12 = gemm_big.hip configs
+void gemm_set_nt_variant(int v);  // 0 auto, 1 = 128x128, 10 / 11 / 12 / 14 / 17-23 = gemm_big.hip configs (gemm.hip launch_nt_t)
 void gemm_set_tile192(int v);     // auto mode: 1 = 192x160 tiles for the whole-K N = 800 dgrads (BIG_192x160_K64)
 void gemm_set_k64(int v);         // auto mode: 1 = 256x160 GEMMs run on 64-deep ring slots (BIG_256x160_K64)
-void gemm_set_big_impl(int v);    // auto mode: 1 = gemm_big.hip family (default), 0 = round-1 big-tile kernel
+void gemm_set_big_impl(int v);    // auto mode: 1 = gemm_big.hip family (default), 2 = without the 256x128 pairs, 0 = 128x128 kernel only
 void gemm_set_tile128x160(int v);  // auto mode: 1 (default) = 128x160 tiles (two workgroups per CU) for the short-K N = 800 GEMMs, 0 = 256x128
-void gemm_set_sk_sym(int v);      // 1 = allow the symmetric 2-way split-K finish where a caller asks for it (GemmParams::sk_sym); 0 (default) = never
 void gemm_set_splitk_max(int v);  // in-kernel split-K of the 256x160 tile: max slices (default 4, 1 = off)
 void gemm_set_nt_band(int band);   // NT tile band height (1 = row-major)

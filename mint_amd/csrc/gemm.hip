@@ -490,251 +490,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_fast_kernel(const GemmParams p
   run_epilogue<EPI>(p, acc, m0, n0, wm, wn, lane, bc.z);
 }
 
-// ------------------------------------------------------------------------------------------
-// Stage image of the big-tile kernel's LDS ring: [rows][32 k] = 64-byte rows; logical 16-byte chunk c of
-// row r sits at position c ^ G[(r>>2)&3], G = {0,2,3,1}: every ds_read_b128 service group (rows {0-3,12-15}
-// of one k-chunk plus rows {4-11} of the next) lands on 16 distinct 16-byte bank slots.  Stages are
-// retired with COUNTED vmcnt waits (wait_stages): NSTAGE-1 stages stay in flight across the barriers.
-// ------------------------------------------------------------------------------------------
-DEVINL int ring_g(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
-
-template <int BKR>
-DEVINL int ring_swz(int row) {
-  if constexpr (BKR == 64) return row & 7;
-  else return ring_g(row);
-}
-template <int BKR>
-DEVINL bf16x8 ring_frag(const unsigned char* tile, int row, int chunk) {
-  return *reinterpret_cast<const bf16x8*>(tile + row * (BKR * 2) + ((chunk ^ ring_swz<BKR>(row)) << 4));
-}
-
-template <int N>
-DEVINL void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// wait until at most `stages_after` later stages (LPS loads each) are still in flight
-template <int LPS>
-DEVINL void wait_stages(int stages_after) {
-  switch (stages_after) {
-    case 0: wait_vmcnt<0>(); break;
-    case 1: wait_vmcnt<LPS>(); break;
-    case 2: wait_vmcnt<2 * LPS>(); break;
-    case 3: wait_vmcnt<3 * LPS>(); break;
-    default: wait_vmcnt<4 * LPS>(); break;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// big-tile NT: (32*MR) x 256 block tile, 8 waves = 2 (M) x 4 (N), each wave a (16*MR) x 64 sub-tile
-// (MR x 4 MFMA tiles, MR = 8 or 9), 32-deep K stages in a 4-deep LDS ring with counted vmcnt.
-// Why: the 128x128 / 4-wave kernel reads 8 fragments from LDS per 16 MFMAs and stages 64 FLOP per
-// LDS-DMA byte; here a wave reads MR+4 fragments per 4*MR MFMAs (0.36 vs 0.5 per MFMA) and a stage
-// carries 2x the FLOPs per DMA byte, so the LDS pipe and the DMA issue slots stop being the limit.
-// One workgroup per CU (136 KiB of LDS): the tile height is picked so that the grid is <= 256
-// workgroups (M = 5760 -> MR = 9: 20 x 12 tiles of 288 x 256 for the FFN1 shape).
-// Stage image: [rows][32 k] 64-byte rows, chunk swizzle ring_g (above).
-// ------------------------------------------------------------------------------------------
-template <int EPI, int MR>
-__global__ __launch_bounds__(512, 1) void gemm_nt_big_kernel(const GemmParams p) {
-  constexpr int BMB = 32 * MR, BNB = 256;
-  constexpr int NSTAGE = 4, DIST = NSTAGE - 1;
-  constexpr int A_PIECES = BMB * 64 / 1024, B_PIECES = BNB * 64 / 1024;  // 1 KiB = 16 rows x 64 B
-  constexpr int A_BYTES = A_PIECES * 1024, STAGE_BYTES = A_BYTES + B_PIECES * 1024;
-  constexpr int NPIECE = A_PIECES + B_PIECES;  // 34 (MR = 9) or 32 (MR = 8)
-  constexpr int LPS_LO = NPIECE / 8, EXTRA = NPIECE % 8;  // waves < EXTRA issue one more piece
-  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_big[];
-  unsigned char* smem = smem_big;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-role branches stay uniform
-  const int wm = wave >> 2, wn = wave & 3;
-
-  const int tn = (p.N + BNB - 1) / BNB, tm = (p.M + BMB - 1) / BMB;
-  int m0, n0;
-  {
-    const int nwg = gridDim.x, orig = blockIdx.x;
-    const int xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    // bands of 4 m-tiles, m fastest: the ~32 tiles of an XCD form a near-square patch
-    const int band = 4, per = band * tn;
-    const int b = id / per, w = id - b * per;
-    const int hb = min(band, tm - b * band);
-    m0 = (b * band + w % hb) * BMB;
-    n0 = (w / hb) * BNB;
-  }
-  const int nk = p.K / 32;
-
-  // DMA pieces of this wave: piece index q in [0, NPIECE): q < A_PIECES -> A rows q*16.., else B rows
-  const int npc = LPS_LO + (wave < EXTRA ? 1 : 0);
-  const int lrow = lane >> 2;                                  // row inside the 16-row piece
-  const int lchunk = (lane & 3) ^ ring_g(lrow);                // logical 16-byte chunk this lane fetches
-  const bf16_t* src[LPS_LO + 1];
-  int dst[LPS_LO + 1];
-#pragma unroll
-  for (int i = 0; i < LPS_LO + 1; ++i) {
-    const int q = (i < LPS_LO) ? wave * LPS_LO + i : 8 * LPS_LO + wave;  // extras: pieces 8*LPS_LO..
-    const int qq = min(q, NPIECE - 1);
-    if (qq < A_PIECES) {
-      src[i] = p.A + (size_t)min(m0 + qq * 16 + lrow, p.M - 1) * p.lda + lchunk * 8;
-      dst[i] = qq * 1024;
-    } else {
-      src[i] = p.B + (size_t)min(n0 + (qq - A_PIECES) * 16 + lrow, p.N - 1) * p.ldb + lchunk * 8;
-      dst[i] = A_BYTES + (qq - A_PIECES) * 1024;
-    }
-  }
-  auto stage = [&](int kt) {
-    unsigned char* base = smem + (kt % NSTAGE) * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < LPS_LO; ++i) glds16(src[i] + kt * 32, base + dst[i]);
-    if (EXTRA && wave < EXTRA) glds16(src[LPS_LO] + kt * 32, base + dst[LPS_LO]);
-  };
-  auto wait_for = [&](int stages_after) {  // wave-uniform: this wave has npc loads per stage
-    if (EXTRA && wave < EXTRA) wait_stages<LPS_LO + 1>(stages_after);
-    else wait_stages<LPS_LO>(stages_after);
-  };
-
-  f32x4 acc[MR][4];
-#pragma unroll
-  for (int i = 0; i < MR; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-#pragma unroll
-  for (int s2 = 0; s2 < DIST; ++s2)
-    if (s2 < nk) stage(s2);
-  wait_for(min(DIST - 1, nk - 1));
-  __builtin_amdgcn_s_barrier();  // stage 0 landed
-
-  // Two wave groups (wm = 0 / 1; each SIMD holds one wave of each) run half a step apart: while one
-  // group issues its DMA pieces and reads its MR + 4 fragments from LDS, the other multiplies the
-  // fragments it read in the previous phase - the LDS pipe and the MFMA pipe of a SIMD are busy at
-  // the same time instead of taking turns.  Two barriers per K step keep the phases aligned:
-  //   phase 2k   : group 0 stages k+3 and reads k      | group 1 multiplies k-1
-  //   phase 2k+1 : group 0 multiplies k                | group 1 stages k+3 and reads k
-  // Both groups run the same loop body; group 1 simply enters it one barrier later.  Every wave
-  // retires its own pieces of stage k+1 (counted vmcnt) before the barrier that ends phase 2k+1 -
-  // after its multiply for group 0, after its reads for group 1 - and its fragment reads (lgkmcnt)
-  // before the barrier that ends its read phase, so a ring slot is only re-armed after both groups
-  // are done with it.
-  bf16x8 af[MR], bfr[4];
-  auto read_frags = [&](int kt) {
-    if (kt + DIST < nk) stage(kt + DIST);
-    const unsigned char* As = smem + (kt % NSTAGE) * STAGE_BYTES;
-    const unsigned char* Bs = As + A_BYTES;
-    const int chunk = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = ring_frag<32>(Bs, wn * 64 + j * 16 + (lane & 15), chunk);
-#pragma unroll
-    for (int i = 0; i < MR; ++i) af[i] = ring_frag<32>(As, wm * (16 * MR) + i * 16 + (lane & 15), chunk);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  auto multiply = [&]() {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < MR; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = kSwap<EPI> ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
-    __builtin_amdgcn_s_setprio(0);
-  };
-  if (wm == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one phase behind group 0
-  for (int kt = 0; kt < nk; ++kt) {
-    read_frags(kt);
-    if (wm == 1 && kt + 1 < nk) wait_for(min(DIST - 1, nk - 2 - kt));
-    __builtin_amdgcn_s_barrier();
-    multiply();
-    if (wm == 0 && kt + 1 < nk) wait_for(min(DIST - 1, nk - 2 - kt));
-    __builtin_amdgcn_s_barrier();
-  }
-  if (wm == 0) __builtin_amdgcn_s_barrier();
-  EpiParams ep = p.ep;
-  ep.z = 0;
-  static_assert(kSwap<EPI>, "big-tile kernel: swapped MFMA roles only");
-  // bf16 outputs leave through LDS: in the MFMA layout a lane owns 4 consecutive columns (8 bytes) and a
-  // wave store covers 16 rows x 32 bytes; with one workgroup per CU nothing hides that 35-70 MB burst.
-  // Each wave re-shapes its 144 x 64 sub-tile in a private, XOR-swizzled piece of the (now idle) stage
-  // ring, 48 / 64 rows at a time, and stores 16 bytes per lane = whole 128-byte row segments
-  // (FFN1 plain epilogue 39.4 -> 32.6 us).
-  constexpr bool kStaged = (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_GELU_BWD);
-  if constexpr (kStaged) {
-    constexpr int NOUT = (EPI == EPI_BIAS_GELU) ? 2 : 1;
-    const bool aligned = !(p.N & 7) && !(ep.ldo0 & 7) && (NOUT == 1 || !(ep.ldo1 & 7)) &&
-                         (EPI != EPI_GELU_BWD || !(ep.ldp & 7));
-    if (aligned) {
-      constexpr int CH = (MR % 3 == 0) ? 3 : 4;  // MFMA row-blocks per pass: 9 = 3 x 3, 8 = 2 x 4
-      constexpr int REG = CH * 16 * 128;          // bytes of one staged output per wave
-      unsigned char* stg = smem + wave * (NOUT * REG);
-      const int wrow0 = m0 + wm * (16 * MR), wcol0 = n0 + wn * 64;
-#pragma unroll
-      for (int c = 0; c < MR / CH; ++c) {
-        if constexpr (EPI == EPI_GELU_BWD) {
-          // the saved pre-activation comes in the same way it goes out: whole 128-byte row segments
-          // into the staging image, then each lane picks its 4 values at the offset it will overwrite
-#pragma unroll
-          for (int rr = 0; rr < CH * 2; ++rr) {
-            const int lr = rr * 8 + (lane >> 3), ch = lane & 7;
-            const int row = min(wrow0 + c * CH * 16 + lr, p.M - 1), col = wcol0 + ch * 8;
-            bf16x8 pv = {};
-            if (col < p.N) pv = *reinterpret_cast<const bf16x8*>(ep.pre + (size_t)row * ep.ldp + col);
-            *reinterpret_cast<bf16x8*>(stg + lr * 128 + ((ch ^ (lr & 7)) << 4)) = pv;
-          }
-        }
-#pragma unroll
-        for (int ii = 0; ii < CH; ++ii) {
-          const int i = c * CH + ii;
-          const int lr = ii * 16 + (lane & 15);  // row inside this pass
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int lc = j * 16 + (lane >> 4) * 4;  // column inside the 64-wide wave tile
-            const int col = wcol0 + lc;
-            const f32x4 v = acc[i][j];
-            bf16x4 o0, o1;
-            if constexpr (EPI == EPI_BF16) {
-              o0 = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            } else if constexpr (EPI == EPI_BIAS_GELU) {
-              float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-              if (col < p.N) b = *reinterpret_cast<const float4*>(ep.bias + col);
-              const float x0 = v[0] + b.x, x1 = v[1] + b.y, x2 = v[2] + b.z, x3 = v[3] + b.w;
-              o0 = bf16x4{(bf16_t)x0, (bf16_t)x1, (bf16_t)x2, (bf16_t)x3};
-              o1 = bf16x4{(bf16_t)gelu_tanh(x0), (bf16_t)gelu_tanh(x1), (bf16_t)gelu_tanh(x2), (bf16_t)gelu_tanh(x3)};
-            } else {  // EPI_GELU_BWD
-              const bf16x4 pv = *reinterpret_cast<const bf16x4*>(
-                  stg + lr * 128 + ((((lc >> 3) ^ (lr & 7))) << 4) + (lc & 7) * 2);
-              o0 = bf16x4{(bf16_t)(v[0] * gelu_tanh_grad((float)pv[0])), (bf16_t)(v[1] * gelu_tanh_grad((float)pv[1])),
-                          (bf16_t)(v[2] * gelu_tanh_grad((float)pv[2])), (bf16_t)(v[3] * gelu_tanh_grad((float)pv[3]))};
-            }
-            // 16-byte chunk (lc / 8) of row lr sits at chunk position (lc / 8) ^ (lr & 7)
-            const int off = lr * 128 + ((((lc >> 3) ^ (lr & 7))) << 4) + (lc & 7) * 2;
-            *reinterpret_cast<bf16x4*>(stg + off) = o0;
-            if constexpr (NOUT == 2) *reinterpret_cast<bf16x4*>(stg + REG + off) = o1;
-          }
-        }
-#pragma unroll
-        for (int rr = 0; rr < CH * 2; ++rr) {
-          const int lr = rr * 8 + (lane >> 3), ch = lane & 7;
-          const int row = wrow0 + c * CH * 16 + lr, col = wcol0 + ch * 8;
-          const int off = lr * 128 + ((ch ^ (lr & 7)) << 4);
-          const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(stg + off);
-          if (row < p.M && col < p.N) {
-            if (NOUT == 1 || ep.out0) *reinterpret_cast<bf16x8*>((bf16_t*)ep.out0 + (size_t)row * ep.ldo0 + col) = v0;
-            if constexpr (NOUT == 2) {
-              const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(stg + REG + off);
-              *reinterpret_cast<bf16x8*>((bf16_t*)ep.out1 + (size_t)row * ep.ldo1 + col) = v1;
-            }
-          }
-        }
-      }
-      return;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < MR; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = m0 + wm * (16 * MR) + i * 16 + (lane & 15);
-      const int col0 = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
-      epilogue_store<EPI>(ep, p.M, p.N, row, col0, acc[i][j]);
-    }
-}
+// (Round 6: the round-1 big-tile kernel gemm_nt_big_kernel - nt variants 6 / 7, big_impl = 0 - was removed; gemm_big.hip
+// generalised it in round 2 and has been the only big-tile path of the engine since.  git history: round 5.)
 
 // ------------------------------------------------------------------------------------------
 // fast TN: A[k*lda + m], B[k*ldb + n]; requires K % 64 == 0
@@ -870,10 +627,10 @@ __global__ __launch_bounds__(256, 2) void gemm_generic_kernel(const GemmParams p
 }
 
 int g_nt_band = 8;  // tile band height of the 128x128 NT kernel (bench knob; measured: 8 >= 4 > row-major)
-// 0 auto; 1 = 128x128 kernel; 6 / 7 = round-1 big-tile kernel 288x256 / 256x256 (gemm_nt_big_kernel);
+// 0 auto; 1 = 128x128 kernel;
 // 10 / 11 / 12 = big-tile family of gemm_big.hip at 288x256 / 256x256 / 256x160 (bench/test knob)
 int g_nt_variant = 0;
-int g_big_impl = 1;  // auto mode: 1 = gemm_big.hip family, 0 = round-1 big kernel (A/B knob)
+int g_big_impl = 1;  // auto mode: 1 = gemm_big.hip family incl. the 256x128 pairs, 2 = without them (A/B knob), 0 = 128x128 kernel only
 int g_k64 = 3;  // auto mode: 64-deep ring slots (bit 0: the 256x160 tile, bit 1: 288x256 / 256x256); 0 = round-2 32-deep slots
 int g_splitk_max = 4;  // in-kernel split-K of the 256x160 tile when the caller hands in a workspace (1 = off)
 int g_tile192 = 0;     // auto mode knob (debug option tile192): whole-K N = 800 GEMMs without a split-K workspace on 192x160 tiles when
@@ -893,10 +650,6 @@ int band_for(int tiles, int tm, int bm, int bn) {
   return band;
 }
 
-int g_sk_sym = 0;  // OPT-IN (debug option sk_sym / gemm_set_sk_sym(1)): the symmetric 2-way split-K finish spins on its peer slice, which
-                   // is only safe while nothing else can keep one of the launch's workgroups off the chip (a second handle, another
-                   // process, a CU mask, RCCL kernels - none of which the engine can see); round 5 measured it at 0.02 ms per step,
-                   // inside the box spread (profiles/r05_ab_symmetric_splitk.txt).  Round 6: off unless asked for.
 // short-K N = 800 GEMMs (out-projection forward / dgrad) on 128x160 instead of 256x128 tiles, two workgroups per CU either way:
 // 45 x 5 = 225 workgroups instead of 23 x 7 = 161 (with 12.5 % column padding) at M = 5760, so the epilogue streams from 225
 // CUs.  Round 5: stand-alone 21.2 -> 18.8 us (+ residual), 14.3 -> 13.1 us (bf16); in the step 26.0 -> 25.0 and 28.2 -> 25.6 us
@@ -918,13 +671,11 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
   if (p.splitk > 1) variant = 1;
   if constexpr (kBigEpi<EPI>) {
     const bool ws = p.sk_slab && p.sk_cnt && g_splitk_max > 1 && p.splitk == 1;
-    int cfg = -1, old_mr = 0;
+    int cfg = -1;
     if (variant >= 10 && variant <= 12) cfg = variant - 10;
     else if (variant == 14) cfg = BIG_256x128;
     else if (variant == 17)  // 64-deep slots need whole lines in memory: row pitch >= K rounded up to 64
       cfg = (p.lda >= ((p.K + 63) & ~63) && p.ldb >= ((p.K + 63) & ~63)) ? BIG_256x160_K64 : BIG_256x160;
-    else if (variant == 6) old_mr = 9;
-    else if (variant == 7) old_mr = 8;
     else if (variant == 0) {
       // Big tiles (one 8-wave workgroup per CU) are taken when their rounds of 256 workgroups are well
       // filled, counting tile padding: useful outputs / (rounds * 256 * tile area) >= 0.6 - e.g. M = 5760,
@@ -938,9 +689,8 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
       const int t160 = ((p.N + 159) / 160) * ((p.M + 255) / 256);
       const int t128 = ((p.N + 127) / 128) * ((p.M + 255) / 256);
       const bool n800 = (p.N % 160 == 0 && p.N <= 960);
-      if (e9 >= 0.6 || e8 >= 0.6) {
-        if (g_big_impl) cfg = (e8 > e9) ? BIG_256x256 : BIG_288x256;
-        else old_mr = (e8 > e9) ? 8 : 9;
+      if ((e9 >= 0.6 || e8 >= 0.6) && g_big_impl) {
+        cfg = (e8 > e9) ? BIG_256x256 : BIG_288x256;
       } else if (g_big_impl && n800 && p.K >= 1536 && (t160 >= 100 || (ws && t160 >= 32))) {
         cfg = BIG_256x160;  // long K: the in-kernel split-K (with a workspace) fills the chip
       } else if (g_big_impl && n800 && t160 > 160 && t160 <= 256) {
@@ -980,15 +730,6 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
       // pays from ~24 stages (768 k) per slice - K = 3072 / 2400 yes, K = 800 no
       while (sk > 1 && (p.K / 32) / sk < 24) --sk;
       if (sk > 1) p.splitk = sk;
-      // symmetric finish: every workgroup of the launch must be resident at once (one per CU: 156 KiB of LDS each)
-      static const int n_cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n;
-      }();
-      if (!(sk == 2 && g_sk_sym && t160 * 2 <= n_cus)) p.sk_sym = 0;
-    } else {
-      p.sk_sym = 0;
     }
     if (cfg >= 0 && (EPI != EPI_HEADS || (p.M < 65536 && p.N < 65536))) {
       int bm = 0, bn = 0;
@@ -996,30 +737,6 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
       const int tm = (p.M + bm - 1) / bm, tnn = (p.N + bn - 1) / bn;
       p.band = user_band > 0 ? user_band : band_for(tm * tnn, tm, bm, bn);
       return launch_big_nt(cfg, EPI, p, s);
-    }
-    if (old_mr == 9) {
-      constexpr int LDSB = 4 * (288 + 256) * 64;
-      static bool once = false;
-      if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<EPI, 9>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        once = true;
-      }
-      FACT_LAUNCH((gemm_nt_big_kernel<EPI, 9>), dim3(((p.N + 255) / 256) * ((p.M + 287) / 288)), dim3(512),
-                         LDSB, s, p);
-      return 0;
-    }
-    if (old_mr == 8) {
-      constexpr int LDSB = 4 * (256 + 256) * 64;
-      static bool once = false;
-      if (!once) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_big_kernel<EPI, 8>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-        once = true;
-      }
-      FACT_LAUNCH((gemm_nt_big_kernel<EPI, 8>), dim3(((p.N + 255) / 256) * ((p.M + 255) / 256)), dim3(512),
-                         LDSB, s, p);
-      return 0;
     }
   }
   FACT_LAUNCH(gemm_nt_fast_kernel<EPI>, dim3(tiles128 * p.splitk), dim3(256), 0, s, p);
@@ -1054,7 +771,6 @@ void gemm_set_tile192(int v) { g_tile192 = v; }
 void gemm_set_big_impl(int v) { g_big_impl = v; }
 void gemm_set_k64(int v) { g_k64 = v; }
 void gemm_set_splitk_max(int v) { g_splitk_max = v < 1 ? 1 : (v > 4 ? 4 : v); }
-void gemm_set_sk_sym(int v) { g_sk_sym = v; }
 void gemm_set_tile128x160(int v) { g_tile128x160 = v; }
 void gemm_set_nt_band(int band) { g_nt_band = band; }
 

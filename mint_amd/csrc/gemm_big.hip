@@ -233,16 +233,9 @@ DEVINL void tn_reads(const unsigned (&ta)[C::MR][(C::NSTAGE + 1) / 2], const uns
 // -------------------------------------------------------------------------------------------------
 template <int S>
 struct SlotC { static constexpr int value = S; };
-#ifndef BIG_DMA_FIRST
-#define BIG_DMA_FIRST 0  // 1 = round-2a order (DMA issues ahead of the fragment reads); A/B build knob
-#endif
-constexpr int DMA_FIRST = BIG_DMA_FIRST;
-#ifndef BIG_PRIO_MODE
-#define BIG_PRIO_MODE 0  // A/B build knob: 0 = s_setprio 1 around every multiply phase (shipped), 1 = no priority changes,
-#endif                   // 2 = static s_setprio 1 for the second-dispatched wave group only, 3 = ... for the first group only
-#ifndef BIG_DMA_IN_MFMA
-#define BIG_DMA_IN_MFMA 0  // A/B build knob: this many of a wave's LDS-DMA pieces per stage are issued from inside
-#endif                     // its multiply phase (spread between the MFMAs) instead of its read phase
+// (Rounds 2-5 carried build knobs here - DMA issues ahead of the fragment reads, static / no s_setprio, DMA pieces issued from
+// inside the multiply phase, write-through / non-temporal epilogue stores: all measured neutral or worse, DESIGN section 6 -
+// removed in round 6; what is left is the shipped schedule.)
 
 // CS (TN only): the waves with `do_cs` also accumulate cs[x] += X_x * ones per K step - the column sums over k of the operand
 // on the MFMA-A side (SWAP: the B units bfr[j], else the A units af[i]); row r of cs[x] in every lane column is
@@ -270,26 +263,6 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
     if (extra) wait_vmcnt<(DIST - 1) * (LPS_LO + 1)>();
     else wait_vmcnt<(DIST - 1) * LPS_LO>();
   };
-  // BIG_DMA_IN_MFMA: the last PM pieces of a stage are issued during the multiply phase.  Group 0 waits at the end of
-  // that phase (all pieces of stage k+DIST issued: same count as above); group 1 waits at the end of its READ phase,
-  // when only the first LPS - PM pieces of stage k+DIST are out.
-  constexpr int PM = BIG_DMA_IN_MFMA < LPS_LO ? BIG_DMA_IN_MFMA : LPS_LO;
-  auto stage_head = [&](auto slot_c, bool more) {  // pieces [0, LPS_LO - PM) + the extra piece
-    constexpr int SLOT = decltype(slot_c)::value;
-    unsigned char* base = smem + SLOT * STAGE;
-#pragma unroll
-    for (int i = 0; i < LPS_LO - PM; ++i) {
-      glds16(reinterpret_cast<const bf16_t*>(sptr[i] + voff[i]), base + dst[i]);
-      sptr[i] += more ? sadv[i] : 0u;
-    }
-    if (extra) glds16(reinterpret_cast<const bf16_t*>(sptr[LPS_LO] + voff[LPS_LO]), base + dst[LPS_LO]);
-    sptr[LPS_LO] += more ? sadv[LPS_LO] : 0u;
-  };
-  auto wait_ahead_g1 = [&]() {
-    if (extra) wait_vmcnt<(DIST - 2) * (LPS_LO + 1) + (LPS_LO + 1 - PM)>();
-    else wait_vmcnt<(DIST - 2) * LPS_LO + (LPS_LO - PM)>();
-  };
-
 #pragma unroll
   for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -340,7 +313,6 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
   auto body = [&](auto slot_c, int kt) {
     constexpr int SLOT = decltype(slot_c)::value;
     constexpr int NEXT = (SLOT + DIST) % NST;  // ring slot of stage kt + DIST (= the slot stage kt - 1 used)
-    if constexpr (DMA_FIRST == 1) stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
     // fragment reads first, the DMA issues of stage kt+DIST (another ring slot) behind them: the ~60-100 cycles
     // each LDS-DMA instruction takes to issue then cover the LDS latency of the reads instead of preceding it
     if constexpr (!TN) {
@@ -348,20 +320,14 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
       for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(smem + b_nt[SLOT] + j * 1024);
 #pragma unroll
       for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const bf16x8*>(smem + a_nt[SLOT] + i * 1024);
-      if constexpr (DMA_FIRST == 0) {
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (PM > 0) stage_head(SlotC<NEXT>{}, kt + DIST + 1 < nk);
-        else stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     } else {
       constexpr int SO = (SLOT & 1) * STAGE, PAIR = SLOT / 2;
       bf16x4 blo[NR], bhi[NR], alo[MR], ahi[MR];
       tn_reads<C, SO, PAIR>(ta, tb, alo, ahi, blo, bhi);
-      if constexpr (DMA_FIRST == 0) {
-        if constexpr (PM > 0) stage_head(SlotC<NEXT>{}, kt + DIST + 1 < nk);
-        else stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
-      }
+      stage(SlotC<NEXT>{}, kt + DIST + 1 < nk);
       // the asm reads are invisible to hipcc's counters: retire them by hand and pin the order
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
@@ -370,32 +336,13 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
 #pragma unroll
       for (int i = 0; i < MR; ++i) af[i] = __builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7);
     }
-    if (grp == 1) {
-      if constexpr (PM > 0) wait_ahead_g1();
-      else wait_ahead();
-    }
+    if (grp == 1) wait_ahead();
     __builtin_amdgcn_s_barrier();
-    if constexpr (BIG_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
-        if constexpr (PM > 0) {
-          // piece q of the tail goes out behind MFMA number (q + 1) * MR * NR / (PM + 1)
-          const int t = i * NR + j + 1;
-#pragma unroll
-          for (int q = 0; q < PM; ++q)
-            if (t == (q + 1) * MR * NR / (PM + 1)) {
-              constexpr int SLOTN = NEXT;
-              const int pi = LPS_LO - PM + q;
-              __builtin_amdgcn_sched_barrier(0);
-              glds16(reinterpret_cast<const bf16_t*>(sptr[pi] + voff[pi]), smem + SLOTN * STAGE + dst[pi]);
-              sptr[pi] += (kt + DIST + 1 < nk) ? sadv[pi] : 0u;
-              __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-      }
+      for (int j = 0; j < NR; ++j) acc[i][j] = SWAP ? mfma16(bfr[j], af[i], acc[i][j]) : mfma16(af[i], bfr[j], acc[i][j]);
     if constexpr (CS) {
       if (do_cs) {  // wave-uniform
         const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
@@ -403,15 +350,10 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
         for (int x = 0; x < (SWAP ? NR : MR); ++x) cs[x] = mfma16(SWAP ? bfr[x] : af[x], ones, cs[x]);
       }
     }
-    if constexpr (BIG_PRIO_MODE == 0) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
     if (grp == 0) wait_ahead();
     __builtin_amdgcn_s_barrier();
   };
-  if constexpr (BIG_PRIO_MODE == 2) {
-    if (grp == 1) __builtin_amdgcn_s_setprio(1);
-  } else if constexpr (BIG_PRIO_MODE == 3) {
-    if (grp == 0) __builtin_amdgcn_s_setprio(1);
-  }
   if (grp == 1) __builtin_amdgcn_s_barrier();  // group 1 runs one phase behind group 0
   for (int kt = 0; kt < nk; kt += NST) {
     body(SlotC<0>{}, kt);
@@ -421,7 +363,6 @@ DEVINL void big_mainloop(unsigned char* smem, const char* (&sptr)[C::LPS_LO + 1]
       if (kt + 3 < nk) body(SlotC<3>{}, kt + 3);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
-  if constexpr (BIG_PRIO_MODE >= 2) __builtin_amdgcn_s_setprio(0);
   wait_vmcnt<0>();  // the run-ahead stages past the end of K: landed before the ring is reused for staging
   __builtin_amdgcn_s_barrier();
 }
@@ -733,24 +674,12 @@ DEVINL unsigned fastdiv(unsigned x, unsigned magic) { return __umulhi(x, magic);
 // of the launch).  Staging rows carry one 16-byte pad chunk (conflict-free ds_write_b128, 2-way
 // ds_write_b64, linear ds_read_b128).
 // -------------------------------------------------------------------------------------------------
-// 16-byte global store of an epilogue row chunk.  BIG_EPI_WT (A/B build knob, tools/build_variant.sh): 0 = plain store
-// (the line stays - dirty - in the XCD's write-back L2 until it is evicted or the kernel ends: every launch of this
-// family ends with the write-back of whatever part of its 9-70 MB of output is still in the 32 MB of L2, and the next,
-// dependent launch waits for it); 1 = write-through (sc1: the line leaves L2 with the store); 2 = non-temporal.
-#ifndef BIG_EPI_WT
-#define BIG_EPI_WT 0
-#endif
+// 16-byte global store of an epilogue row chunk (plain store; write-through / non-temporal forms were measured in round 5
+// and removed in round 6: profiles/r05_ab_writethrough_epilogue.txt)
 template <typename V>
 DEVINL void st_out16(void* p, V v) {
   static_assert(sizeof(V) == 16, "16-byte chunk");
-#if BIG_EPI_WT == 1
-  const u32x4 w = __builtin_bit_cast(u32x4, v);
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(w) : "memory");
-#elif BIG_EPI_WT == 2
-  __builtin_nontemporal_store(__builtin_bit_cast(u32x4, v), reinterpret_cast<u32x4*>(p));
-#else
   *reinterpret_cast<V*>(p) = v;
-#endif
 }
 
 template <int EPI>
@@ -762,7 +691,7 @@ template <int EPI>
 DEVINL void direct_store(const EpiParams& ep, int M, int N, int row, int col0, f32x4 v);
 
 // accumulator rows (MF-row MFMA tiles) per pass of the staged fp32 epilogue: the largest divisor of MR whose 8 wave regions fit
-// the idle ring (shared by the epilogue and the symmetric split-K finish, which hands each slice whole passes)
+// the idle ring
 template <class C>
 constexpr int f32_pass_rows() {
   constexpr int MR = C::MR, RT = C::MF, STR = C::WCOLS * 4 + 16;
@@ -834,7 +763,8 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
   if constexpr (C::KS == 64) big_mainloop64<C, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
   else big_mainloop<C, false, true>(smem, sptr, sadv, voff, dst, nk, wave, wm, wn, lane, acc);
   // quad jq of accumulator row i: 4 consecutive output columns C::qcol(jq, lane).. of output row i * RT + lrow_t
-  auto quad = [&](int i, int jq) -> f32x4 {
+  // (always_inline: called from a few hundred unrolled sites - out of line, `acc` would live in scratch memory)
+  auto quad = [&](int i, int jq) __attribute__((always_inline)) -> f32x4 {
     if constexpr (C::MF == 32) {
       const f32x16& t = acc[i][jq >> 2];
       const int q = (jq & 3) * 4;
@@ -843,7 +773,7 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
       return acc[i][jq];
     }
   };
-  auto add_quad = [&](int i, int jq, f32x4 v) {
+  auto add_quad = [&](int i, int jq, f32x4 v) __attribute__((always_inline)) {
     if constexpr (C::MF == 32) {
       f32x16& t = acc[i][jq >> 2];
       const int q = (jq & 3) * 4;
@@ -853,9 +783,6 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     }
   };
 
-  // rows of the wave tile this workgroup runs the epilogue for: all (-1), or - symmetric 2-way split-K finish - the
-  // accumulator rows i < MR / 2 (0) or i >= MR / 2 (1)
-  int epi_half = -1;
   if (p.splitk > 1) {
     // In-launch split-K finish (cdna_hip_programming.md 5 "in-launch split-K reduction", write-through form):
     // every slice publishes its fp32 partial tile with sc1 (write-through) 16-byte stores in fragment order
@@ -863,55 +790,42 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
     // slice that draws the last ticket adds its peers' partials (sc1 loads behind one agent-scope acquire)
     // and runs the epilogue.  No spinning: an early slice exits.  Placement-independent; the counter is
     // returned to zero by the last arriver.
-    //
-    // SYMMETRIC finish (round 5; GemmParams::sk_sym, 2 slices, fp32 + residual epilogue).  The HBM rate a launch gets grows
-    // with the CUs it holds (tools/cu_stream_probe.hip: 115 CUs 4.1-4.8 TB/s, 230 the chip's rate), and the finish above
-    // runs on HALF the launch's CUs: the last arriver of each tile reads its peer's 164 KB partial, the 82 KB residual rows
-    // and writes 164 KB... while the other slice's CU has already
-    // left.  Here both slices stay: each publishes only the accumulator rows the OTHER one finishes (i >= MR / 2 from
-    // slice 0, i < MR / 2 from slice 1: half the slab traffic), waits for its peer's half (bounded spin on the arrival
-    // counter - the two slices of a tile are neighbouring ids of one launch of <= #CUs one-per-CU workgroups, i.e.
-    // co-resident; the host only sets the flag then), adds it and runs the epilogue passes of its own rows.  Counter:
-    // +1 on arrival (wait for >= 2), +1 when the peer's data has been read; the 4th increment returns it to zero.
+    // (Round 5 added a SYMMETRIC 2-way finish - both slices stay, wait for each other on the counter and each run half the
+    //  epilogue: 0.02 ms per step, inside the box spread, for a spin-wait whose safety needs every workgroup of the launch to
+    //  be resident, which the engine cannot guarantee against other handles / processes / RCCL kernels.  Removed in round 6:
+    //  profiles/r05_ab_symmetric_splitk.txt, git history.)
     constexpr unsigned WG_BYTES = (unsigned)BM * BN * 4;
     char* tile_slabs = reinterpret_cast<char*>(p.sk_slab) + (size_t)tile * p.splitk * WG_BYTES;
     const unsigned lane_off = (unsigned)(wave * MR * NQ * 1024 + lane * 16);
-    // epilogue passes of <= MR / 2 rows that never straddle the halves: the staged fp32 epilogue below runs CH = kF32PassRows
-    // accumulator rows per pass, and a slice must own whole passes
-    constexpr int CHF = f32_pass_rows<C>();
-    constexpr bool SYM_OK = kStagedF32<EPI> && (MR % 2 == 0) && CHF <= MR / 2 && (MR / 2) % CHF == 0;
-    const bool sym = SYM_OK && p.sk_sym && p.splitk == 2;
     {
       const __amdgpu_buffer_rsrc_t mine =
           __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)z * WG_BYTES, 0, WG_BYTES, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        if (sym && ((i >= MR / 2) != (z == 0))) continue;  // (wave-uniform) only the rows the peer will finish
+      for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, quad(i, j)), mine,
                                                  lane_off + (i * NQ + j) * 1024, 0, /*sc1*/ 16);
-      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
     __syncthreads();
     unsigned* flag = reinterpret_cast<unsigned*>(smem);  // the ring is idle: no second __shared__ object
-    if (sym) {
-      if (tid == 0) {
-        __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(p.sk_cnt + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > (1u << 26)) __builtin_trap();  // a peer that never arrives is a launch-geometry bug: fail, do not hang
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      __syncthreads();
+    if (tid == 0)
+      *flag = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = *flag;
+    if (ticket != (unsigned)(p.splitk - 1)) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    for (int zz = 0; zz < p.splitk; ++zz) {
+      if (zz == z) continue;
       const __amdgpu_buffer_rsrc_t peer =
-          __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)(1 - z) * WG_BYTES, 0, WG_BYTES, 0x00020000);
+          __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)zz * WG_BYTES, 0, WG_BYTES, 0x00020000);
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
-        if ((i >= MR / 2) != (z == 1)) continue;  // my rows: i < MR / 2 for slice 0
         u32x4 t[NQ];
 #pragma unroll
         for (int j = 0; j < NQ; ++j)
@@ -919,39 +833,8 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
 #pragma unroll
         for (int j = 0; j < NQ; ++j) add_quad(i, j, __builtin_bit_cast(f32x4, t[j]));
       }
-      __syncthreads();  // every wave holds its peer data (the loads above were waited for by the adds)
-      if (tid == 0) {
-        const unsigned old = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == 3u) __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      epi_half = z;
-    } else {
-      if (tid == 0)
-        *flag = __hip_atomic_fetch_add(p.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      const unsigned ticket = *flag;
-      if (ticket != (unsigned)(p.splitk - 1)) return;
-      if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(p.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      for (int zz = 0; zz < p.splitk; ++zz) {
-        if (zz == z) continue;
-        const __amdgpu_buffer_rsrc_t peer =
-            __builtin_amdgcn_make_buffer_rsrc(tile_slabs + (size_t)zz * WG_BYTES, 0, WG_BYTES, 0x00020000);
-#pragma unroll
-        for (int i = 0; i < MR; ++i) {
-          u32x4 t[NQ];
-#pragma unroll
-          for (int j = 0; j < NQ; ++j)
-            t[j] = __builtin_amdgcn_raw_buffer_load_b128(peer, lane_off + (i * NQ + j) * 1024, 0, /*sc1*/ 16);
-#pragma unroll
-          for (int j = 0; j < NQ; ++j) add_quad(i, j, __builtin_bit_cast(f32x4, t[j]));
-        }
-      }
-      __syncthreads();  // flag word read by everyone before the ring is reused as epilogue staging
     }
+    __syncthreads();  // flag word read by everyone before the ring is reused as epilogue staging
   }
 
   const EpiParams& ep = p.ep;
@@ -1064,9 +947,6 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
       unsigned char* stg = smem + wave * REG;
 #pragma unroll
       for (int c = 0; c < MR / CH; ++c) {
-        // symmetric split-K finish: only the passes of this slice's accumulator rows (CH <= MR / 2 there: a pass never
-        // straddles the halves)
-        if (epi_half >= 0 && ((c * CH >= MR / 2) != (epi_half == 1))) continue;
         const int prow0 = wrow0 + c * CH * RT;
         // the fp32 residual rows of this pass are requested first, whole row segments per wave load; their
         // latency hides behind the accumulator -> LDS re-shape below
@@ -1114,7 +994,6 @@ __global__ __launch_bounds__(C::NW * 64, 2 * C::WGS_PER_CU) void big_nt_kernel(c
   }
 #pragma unroll
   for (int i = 0; i < MR; ++i) {
-    if (epi_half >= 0 && ((i >= MR / 2) != (epi_half == 1))) continue;
 #pragma unroll
     for (int j = 0; j < NQ; ++j)
       direct_store<EPI>(ep, p.M, p.N, wrow0 + i * RT + lrow_t, wcol0 + C::qcol(j, lane), quad(i, j));
@@ -1694,10 +1573,5 @@ int launch_big_tn_group(TnGroup g, hipStream_t s, int parts) {
   if (g_tn_cfg == 1) return launch_big_tn_group_t<Cfg160x256, 1>(g, s, parts);
   if (g_tn_cfg == 2) return launch_big_tn_group_t<Cfg160x256, 2>(g, s, parts);
   if (g_tn_cfg == 6) return launch_big_tn_group_t<Cfg160x256r6, 2>(g, s, parts);  // interleaved loop, 6-slot ring
-#ifdef BIG_ABLATION
-  if (g_tn_cfg == 3) return launch_big_tn_group_t<Cfg160x256, 3>(g, s, parts);  // interleaved loop without DMA
-  if (g_tn_cfg == 4) return launch_big_tn_group_t<Cfg160x256, 4>(g, s, parts);  // ... without MFMAs
-  if (g_tn_cfg == 5) return launch_big_tn_group_t<Cfg160x256, 5>(g, s, parts);  // ... without fragment reads
-#endif
   return launch_big_tn_group_t<Cfg160x256, 0>(g, s, parts);
 }

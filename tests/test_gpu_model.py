@@ -21,13 +21,12 @@ def continuous_attention():
     kernels, two data-parallel optimizer placements) over several optimizer steps need a forward that is a continuous
     function of the weights at that scale.  The default streaming forward kernel raises its running softmax maximum only
     when a score outgrows it by more than 2^6 (exact by shift invariance, but the bf16 rounding of P is re-rolled whenever
-    a 1-ulp weight difference flips such a decision: 4e-9 -> 3e-3 relative output difference, measured); the LDS-resident
-    family has no such threshold."""
+    a 1-ulp weight difference flips such a decision: 4e-9 -> 3e-3 relative output difference, measured); the tiled reference
+    kernels (standard online softmax; round 6: the round-2/3 resident family this fixture used is gone) have no such threshold."""
     from mint_amd import _lib as L
-    before = L.lib().fact_debug_attn_variant_get()
-    L.lib().fact_debug_attn_variant(1)
+    L.lib().fact_debug_attn_force_tiled(1)
     yield
-    L.lib().fact_debug_attn_variant(before)
+    L.lib().fact_debug_attn_force_tiled(0)
 
 
 def make_config(cfg):

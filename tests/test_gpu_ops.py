@@ -104,12 +104,12 @@ def gemm_path(request):
     L.lib().fact_debug_force_generic_gemm(0)
 
 
-@pytest.fixture(params=[0, 1, 6, 7, 10, 11, 12, 14, 17, 18, 19, 22, 23],
-                ids=["auto", "tile128", "r1big288", "r1big256", "big288x256", "big256x256", "big256x160", "big256x128x2",
+@pytest.fixture(params=[0, 1, 10, 11, 12, 14, 17, 18, 19, 22, 23],
+                ids=["auto", "tile128", "big288x256", "big256x256", "big256x160", "big256x128x2",
                      "big256x160k64", "big288x256k64", "big256x256k64", "m32_256x256", "m32_384x192"])
 def nt_variant(request):
-    """NT kernel choice: the engine's automatic pick, the 128x128 kernel, the round-1 big-tile kernels and
-    every tile config of the big-tile family (gemm_big.hip), forced regardless of the tile-count heuristic."""
+    """NT kernel choice: the engine's automatic pick, the 128x128 kernel and every tile config of the big-tile family
+    (gemm_big.hip; 22 / 23 = the 32x32x16 MFMA tiles of round 6), forced regardless of the tile-count heuristic."""
     L.lib().fact_debug_gemm_nt_variant(request.param)
     yield request.param
     L.lib().fact_debug_gemm_nt_variant(0)
@@ -176,39 +176,6 @@ def test_gemm_nt_splitk_in_kernel(M, N, K):
     finally:
         lib.fact_debug_gemm_splitk_max(4)
     _close(o1, o2, 1e-5, 1e-4, "split vs unsplit")
-
-
-@pytest.mark.parametrize("M,N,K", [(5760, 800, 3072), (5632, 800, 3072), (4000, 800, 1600), (5760, 800, 1600)])
-def test_gemm_nt_splitk_symmetric_finish(M, N, K):
-    """Round 5: 2-way in-kernel split-K whose two slices BOTH stay and each run the fp32 epilogue of half the tile's rows
-    (gemm.h GemmParams::sk_sym) against the exiting finish (last arriver does everything).  Each output element is
-    own-partial + peer-partial in either form - fp32 addition commutes - so the two must agree BIT FOR BIT, bias and
-    residual included; checked over many back-to-back launches with fresh operands (arrival counter returns to zero,
-    no stale slab line), with a ragged last row tile (5760 = 22.5 x 256, 4000 = 15.6 x 256) and against torch.  (Every
-    shape here splits 2 ways; a 3- or 4-way split keeps the exiting finish, whose summation order follows the arrival
-    order and is not reproducible bit for bit.)"""
-    lib = L.lib()
-    g = torch.Generator(device=DEV).manual_seed(23)
-    bias = torch.randn(N, device=DEV, generator=g)
-    for it in range(6):
-        A = _bf(torch.randn(M, K, device=DEV, generator=g))
-        B = _bf(torch.randn(N, K, device=DEV, generator=g) * 0.1)
-        resid = torch.randn(M, N, device=DEV, generator=g)
-        outs = []
-        for sym in (1, 0, 1):
-            lib.fact_debug_gemm_sk_sym(sym)
-            try:
-                o = torch.full((M, N), float("nan"), device=DEV)
-                _gemm_nt(L.EPI_F32_BIAS_RESID, A, B, M, N, K, o, bias=bias, resid=resid)
-            finally:
-                lib.fact_debug_gemm_sk_sym(0)  # the library default since round 6: opt-in only
-            outs.append(o)
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "it %d: symmetric vs exiting finish" % it
-        _close(outs[0], A.float() @ B.float().t() + bias + resid, 1e-4, 2e-3, "symmetric finish it%d" % it)
-        if it == 3:  # a bf16-epilogue launch in between (exiting finish, same counters and slabs)
-            o16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-            _gemm_nt(L.EPI_BF16, A, B, M, N, K, o16)
-            _close(o16, A.float() @ B.float().t(), 1e-2, 1e-2 * math.sqrt(K) * 0.1, "bf16 between symmetric launches")
 
 
 @pytest.mark.parametrize("M,N,K", [(5760, 800, 3072), (5760, 800, 2400), (700, 800, 800), (300, 500, 96), (256, 160, 32),
@@ -599,15 +566,15 @@ def _attn_ref(qkv, B, H, n, dh, scale, dout=None):
     return out.detach(), x.grad
 
 
-@pytest.fixture(params=[0, 1, 2, 3, 4], ids=["resident", "tiled", "streaming", "lean", "lean_pk"])
+@pytest.fixture(params=[0, 1, 2], ids=["default", "tiled_reference", "streaming"])
 def attn_path(request):
-    """The kernel families: LDS-resident (when the head fits), tiled, the streaming 4-wave kernels (128-row blocks,
-    4-slot LDS-DMA ring, lazy-max softmax with MFMA row sums), and the lean LDS-resident backward of round 4 (behind the
-    streaming forward = the engine's default pairing), with scalar and with packed fp32 softmax arithmetic."""
+    """The kernel families left after the round-6 pruning: the default (streaming forward: 128-row blocks, 4-slot LDS-DMA ring,
+    lazy-max softmax with MFMA row sums; lean LDS-resident backward where the head fits, streaming backward otherwise), the
+    tiled reference kernels (standard online softmax), and the streaming kernels everywhere."""
     lib = L.lib()
     before = lib.fact_debug_attn_variant_get()
     lib.fact_debug_attn_force_tiled(1 if request.param == 1 else 0)
-    lib.fact_debug_attn_variant({0: 1, 1: 1, 2: 2, 3: 5, 4: 7}[request.param])
+    lib.fact_debug_attn_variant({0: 5, 1: 5, 2: 2}[request.param])
     yield request.param
     lib.fact_debug_attn_force_tiled(0)
     lib.fact_debug_attn_variant(before)

@@ -12,7 +12,7 @@ from mint_amd import _lib as L
 lib = L.lib()
 dev = "cuda"
 ITERS = int(os.environ.get("ITERS", "20"))
-VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "1,2").split(",")]
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "5,2").split(",")]  # 5 = default pairing, 2 = streaming everywhere
 
 
 def ref(qkv, B, H, n, dh, scale, dout):
@@ -56,7 +56,7 @@ def case(B, H, n, dh, std=3.0):
         e1.record(); e1.synchronize()
         print("B%d H%d n%d dh%d variant %d: op %.1f us  rel err out %.2e dq %.2e dk %.2e dv %.2e finite %s" % (
             B, H, n, dh, v, e0.elapsed_time(e1) / ITERS * 1e3, e_out, errs[0], errs[1], errs[2], fin), flush=True)
-    lib.fact_debug_attn_variant(1)
+    lib.fact_debug_attn_variant(5)
 
 
 if __name__ == "__main__":

@@ -147,7 +147,7 @@ if __name__ == "__main__":
             nt_case(Me, 800, 3072, L.EPI_F32_BIAS_RESID, [1, 112, 12], "enc FFN2")
             nt_case(Me, 800, 800, L.EPI_F32_BIAS_RESID, [1, 112, 12], "enc out-proj")
             nt_case(Me, 3072, 800, L.EPI_BIAS_GELU, [1, 10, 11, 14], "enc FFN1")
-        nt_case(8192, 8192, 8192, L.EPI_BF16, [1, 7, 11], "8192^3")
+        nt_case(8192, 8192, 8192, L.EPI_BF16, [1, 11, 19], "8192^3")
     if what == "m32":  # round 6: 32x32x16 MFMA tiles (v22 = 256x256, v23 = 384x192) vs the 16x16x32 tiles on 64-deep slots (v19 / v18)
         M = 5760
         for rep in range(2):
