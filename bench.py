@@ -637,14 +637,16 @@ def kernel_table_from_child(args, local_rank, B):
     cmd = [sys.executable, os.path.abspath(__file__), "--kernel-table-child", "--gpus", "1", "--steps", "5", "--warmup", "5",
            "--batch", str(B), "--profile-steps", str(max(1, args.profile_steps)), "--side-stream", str(args.side_stream),
            "--fuse-optimizer", str(args.fuse_optimizer), "--no-cpu-baseline"]
-    try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        for line in reversed(r.stdout.strip().splitlines()):
-            if line.startswith("{") and "kernel_table_child" in line:
-                return json.loads(line)
-        print("kernel-table child failed (rc %d): %s" % (r.returncode, (r.stderr or r.stdout)[-2000:]), file=sys.stderr)
-    except Exception as e:
-        print("kernel-table child failed: %r" % (e,), file=sys.stderr)
+    for attempt in range(2):
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+            for line in reversed(r.stdout.strip().splitlines()):
+                if line.startswith("{") and "kernel_table_child" in line:
+                    return json.loads(line)
+            print("kernel-table child failed (rc %d, attempt %d): %s" % (r.returncode, attempt, (r.stderr or r.stdout)[-2000:]),
+                  file=sys.stderr)
+        except Exception as e:
+            print("kernel-table child failed (attempt %d): %r" % (attempt, e), file=sys.stderr)
     return None
 
 
@@ -834,6 +836,12 @@ def main():
                     "fwd_tflops": by["attention_fwd"]["achieved"], "fwd_mfma_frac": by["attention_fwd"]["frac"],
                     "bwd_tflops": by["attention_bwd"]["achieved"], "bwd_mfma_frac": by["attention_bwd"]["frac"],
                     "note": "QK^T+PV algorithmic FLOPs / in-step launch time, all 16 layers; MFMA-busy PMC: profiles/"}
+        elif args.profile_steps > 0:
+            # the kernel-table child did not deliver (it never should fail; the headline must not depend on it): a whole-step
+            # roofline object from this process's own clock, marked as such
+            out["roofline"] = {"bound": "mfma", "kernel": "whole train step (kernel-class table unavailable: child process failed)",
+                               "achieved": out["step_tflops"], "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
+                               "frac": out["step_mfma_frac"], "traffic": None}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -100,3 +100,14 @@ def test_gpus_flag_spawns_ranks_only_without_a_launcher(bench):
     assert seen["env"]["GPU_MAX_HW_QUEUES"] == "7" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert seen["env"]["PATH"] == "/bin"
     assert bench.requested_gpus(["--steps", "5", "--gpus", "8"]) == 8 and bench.requested_gpus(["--steps", "5"]) == 1
+
+
+def test_library_selection_of_a_bench_process(bench):
+    """Round 6: the driver's line (--mode train) times the PRODUCTION library; anything that needs the debug surface in the
+    timed process itself - A/B knobs, the kernel-table child, the ar / scaled artefact modes - binds the test / bench build."""
+    assert not bench.wants_debug_build(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    assert not bench.wants_debug_build(["--mode", "train", "--breakdown"])
+    assert bench.wants_debug_build(["--opt", "bias_in_wgrad=0"]) and bench.wants_debug_build(["--opt=wgrad_parts=1"])
+    assert bench.wants_debug_build(["--kernel-table-child", "--steps", "5"])
+    assert bench.wants_debug_build(["--mode", "ar"]) and bench.wants_debug_build(["--mode=scaled"])
+    assert bench.raw_flag(["--steps", "7", "--mode=ar"], "--mode") == "ar" and bench.raw_flag([], "--mode", "train") == "train"
