@@ -654,7 +654,7 @@ int band_for(int tiles, int tm, int bm, int bn) {
 // 45 x 5 = 225 workgroups instead of 23 x 7 = 161 (with 12.5 % column padding) at M = 5760, so the epilogue streams from 225
 // CUs.  Round 5: stand-alone 21.2 -> 18.8 us (+ residual), 14.3 -> 13.1 us (bf16); in the step 26.0 -> 25.0 and 28.2 -> 25.6 us
 // per launch, step 7.574 -> 7.525 ms (3 interleaved rounds, profiles/r05_ab_tile128x160.txt).  0 = the round-2 tile (A/B knob)
-int g_tile128x160 = 1;
+int g_tile128x160 = 1;  // 2 = also the LONG-K N = 800 GEMMs that fall through to 256x128 (the encoder stacks' whole-K dgrads: round-5 behaviour, A/B)
 
 template <int EPI>
 int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
@@ -710,7 +710,7 @@ int launch_nt_t(const GemmParams& p_in, hipStream_t s) {
     if (variant == 21) cfg = BIG_128x160;
     if (variant == 22) cfg = k64_ok ? BIG_256x256_M32 : BIG_256x256;   // 32 x 32 x 16 MFMA tiles (round 6)
     if (variant == 23) cfg = k64_ok ? BIG_384x192_M32 : BIG_288x256;
-    if (variant == 0 && g_tile128x160 && cfg == BIG_256x128 && p.N % 160 == 0 && p.N <= 960 && p.K < 1536 &&
+    if (variant == 0 && g_tile128x160 && cfg == BIG_256x128 && p.N % 160 == 0 && p.N <= 960 && (p.K < 1536 || g_tile128x160 == 2) &&
         (EPI == EPI_F32_BIAS_RESID || EPI == EPI_HEADS || EPI == EPI_BF16))
       cfg = BIG_128x160;  // the SHORT-K N = 800 GEMMs on 128x160 tiles (long K: the tile loses, profiles/r05_tile128x160_long_k.txt)
     if (g_k64 && variant == 0 && k64_ok) {
